@@ -1,0 +1,104 @@
+"""Deterministic synthetic weights and inputs for parity fixtures.
+
+TEST INFRASTRUCTURE ONLY (see restormer_oracle.py).  Everything is drawn from
+``numpy.random.RandomState`` streams so that the fixture generator (which runs
+next to the reference) and the tests (which run without it) rebuild bit-equal
+tensors from a small integer seed instead of shipping megabytes of weights.
+
+Weights follow the scale of the reference's untouched ``nn.Conv2d`` default
+init (uniform in +-1/sqrt(fan_in)); the LayerNorm scale/shift and the attention
+temperature, which the reference leaves at 1/0/1, are drawn non-trivially so
+those code paths carry signal.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import numpy as np
+import torch
+
+from .restormer_oracle import block_param_shapes, model_param_shapes
+
+
+def _draw(rs: np.random.RandomState, name: str, shape: Tuple[int, ...]) -> np.ndarray:
+    n = int(np.prod(shape))
+    leaf = name.split(".")[-1]
+    if "temperature" in name:
+        a = rs.uniform(0.5, 1.5, size=n)
+    elif ".body." in name and "norm" in name and leaf == "weight":
+        a = rs.uniform(0.5, 1.5, size=n)
+    elif ".body." in name and "norm" in name and leaf == "bias":
+        a = rs.normal(0.0, 0.1, size=n)
+    elif leaf == "bias":
+        a = rs.uniform(-0.1, 0.1, size=n)
+    else:
+        fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else shape[0]
+        bound = 1.0 / np.sqrt(max(fan_in, 1))
+        a = rs.uniform(-bound, bound, size=n)
+    return a.astype(np.float32).reshape(shape)
+
+
+def make_state_dict(shapes: List[tuple], seed: int, dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    rs = np.random.RandomState(seed)
+    return {name: torch.from_numpy(_draw(rs, name, shp)).to(dtype) for name, shp in shapes}
+
+
+def make_input(shape: Tuple[int, ...], seed: int, kind: str = "uniform", dtype=torch.float32) -> torch.Tensor:
+    rs = np.random.RandomState(seed)
+    if kind == "uniform":
+        a = rs.uniform(0.0, 1.0, size=shape)
+    else:
+        a = rs.normal(0.0, 1.0, size=shape)
+    return torch.from_numpy(a.astype(np.float32)).to(dtype)
+
+
+# ---- the fixture catalogue --------------------------------------------------
+# TransformerBlock cases: (tag, dim, heads, ln_type, bias, B, H, W)
+BLOCK_CASES = [
+    ("c48h1_wb_nb", 48, 1, "WithBias", False, 2, 16, 24),
+    ("c48h1_bf_b", 48, 1, "BiasFree", True, 2, 16, 24),
+    ("c96h2_wb_nb", 96, 2, "WithBias", False, 2, 16, 24),
+    ("c96h1_wb_nb", 96, 1, "WithBias", False, 2, 16, 24),
+    ("c96h1_wb_b", 96, 1, "WithBias", True, 1, 8, 12),
+    ("c192h4_wb_nb", 192, 4, "WithBias", False, 1, 8, 12),
+    ("c192h4_bf_nb", 192, 4, "BiasFree", False, 1, 8, 12),
+    ("c384h8_wb_nb", 384, 8, "WithBias", False, 1, 4, 6),
+    ("c24h2_wb_b", 24, 2, "WithBias", True, 2, 5, 7),      # ragged: odd H, W, tiny channels
+    ("c12h1_bf_nb", 12, 1, "BiasFree", False, 1, 3, 9),
+]
+FFN_FACTOR = 1.25
+
+# Whole-network cases: (tag, ctor kwargs, input shape)
+MODEL_CASES = [
+    ("dim12_default", dict(inp_channels=4, out_channels=4, dim=12), (1, 4, 32, 40)),
+    ("dim48_rgb", dict(inp_channels=3, out_channels=3, dim=48), (1, 3, 32, 32)),
+    ("dim16_bias_bf", dict(inp_channels=3, out_channels=3, dim=16, bias=True, LayerNorm_type="BiasFree",
+                           num_blocks=[1, 1, 1, 2], num_refinement_blocks=1), (2, 3, 16, 24)),
+]
+
+SUBSAMPLE = 4096      # tensors larger than this are pinned by a fixed subsample + norms
+
+
+def block_case_tensors(case, dtype=torch.float32):
+    tag, dim, heads, ln_type, bias, b, h, w = case
+    seed = 1000 + BLOCK_CASES.index(case)
+    sd = make_state_dict(block_param_shapes(dim, heads, FFN_FACTOR, bias, ln_type), seed, dtype)
+    x = make_input((b, dim, h, w), seed + 500, "normal", dtype)
+    r = make_input((b, dim, h, w), seed + 900, "normal", dtype)      # loss = sum(out * r)
+    return sd, x, r
+
+
+def model_case_tensors(case, dtype=torch.float32):
+    tag, kwargs, shape = case
+    seed = 2000 + MODEL_CASES.index(case)
+    sd = make_state_dict(model_param_shapes(**kwargs), seed, dtype)
+    x = make_input(shape, seed + 500, "uniform", dtype)
+    oshape = (shape[0], kwargs.get("out_channels", 4), shape[2] * 2, shape[3] * 2)
+    tgt = make_input(oshape, seed + 900, "uniform", dtype)
+    return sd, x, tgt
+
+
+def subsample_index(numel: int, seed: int = 7) -> np.ndarray:
+    if numel <= SUBSAMPLE:
+        return np.arange(numel)
+    return np.sort(np.random.RandomState(seed + numel % 9973).choice(numel, SUBSAMPLE, replace=False))
