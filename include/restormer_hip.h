@@ -1,0 +1,212 @@
+/*
+ * restormer_hip.h -- C ABI of the MI355X (gfx950) Restormer TransformerBlock library.
+ *
+ * The reference (JagadeeshAI/SuperResolution) is pure Python: its "operator
+ * interface" for this path is the set of nn.Module forwards in
+ * model/Restromer.py.  Each entry point below replaces the forward (or the
+ * autograd backward) of one of those modules and cites it.  The Python host
+ * layer (superresolution_amd/model/Restromer.py) binds these symbols with
+ * ctypes and re-exposes the reference's constructors and forward signatures.
+ *
+ * Conventions
+ *  - All tensors are device pointers to contiguous fp32 NCHW data unless a
+ *    stride argument says otherwise; "N" is H*W, the pixels of one sample.
+ *  - Inputs are borrowed, outputs are written in place, nothing is retained
+ *    after the call returns.  No entry point allocates or frees device memory,
+ *    synchronises the device or the stream; scratch memory comes in through
+ *    the `workspace` argument, sized by the matching *_workspace_bytes query.
+ *  - `stream` is a hipStream_t (NULL = the default stream); all work of a call
+ *    is enqueued on it in order.
+ *  - Every function returns RST_OK or an error code; rst_last_error() gives the
+ *    message of the last failure on the calling thread.  Arguments are
+ *    validated before anything is launched.
+ *  - Calls on different devices/streams are independent; a workspace must not
+ *    be shared by calls that may overlap in time.
+ */
+#ifndef RESTORMER_HIP_H
+#define RESTORMER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum rst_status {
+    RST_OK = 0,
+    RST_ERR_INVALID = 1,   /* bad shape / null pointer / unsupported size */
+    RST_ERR_HIP = 2,       /* HIP runtime reported an error               */
+    RST_ERR_WORKSPACE = 3  /* workspace pointer null or too small         */
+};
+
+/* Library ABI version (bumped on any signature change). */
+int rst_version(void);
+/* Message of the last failure on this thread ("" if none). */
+const char* rst_last_error(void);
+
+/* ------------------------------------------------------------------------- */
+/* Shapes and parameters of one TransformerBlock                              */
+/* (model/Restromer.py:154-161 constructor; :110-125 Attention; :80-97 FFN).  */
+/* ------------------------------------------------------------------------- */
+typedef struct rst_block_desc {
+    int32_t B, C, H, W;    /* input is B x C x H x W                              */
+    int32_t heads;         /* num_heads; C % heads == 0                           */
+    int32_t hidden;        /* int(C * ffn_expansion_factor), model/Restromer.py:83 */
+    int32_t ln_with_bias;  /* 1: WithBias_LayerNorm, 0: BiasFree_LayerNorm        */
+    int32_t conv_bias;     /* 1: the six convolutions carry a bias                */
+} rst_block_desc;
+
+/* Device pointers named after the reference state-dict entries of a block.
+ * Bias pointers are ignored (may be NULL) when the matching flag is 0. */
+typedef struct rst_block_params {
+    const float* norm1_weight;    /* norm1.body.weight            [C]          */
+    const float* norm1_bias;      /* norm1.body.bias              [C]          */
+    const float* temperature;     /* attn.temperature             [heads]      */
+    const float* qkv_weight;      /* attn.qkv.weight              [3C, C]      */
+    const float* qkv_bias;        /* attn.qkv.bias                [3C]         */
+    const float* qkv_dw_weight;   /* attn.qkv_dwconv.weight       [3C, 9]      */
+    const float* qkv_dw_bias;     /* attn.qkv_dwconv.bias         [3C]         */
+    const float* proj_weight;     /* attn.project_out.weight      [C, C]       */
+    const float* proj_bias;       /* attn.project_out.bias        [C]          */
+    const float* norm2_weight;    /* norm2.body.weight            [C]          */
+    const float* norm2_bias;      /* norm2.body.bias              [C]          */
+    const float* pin_weight;      /* ffn.project_in.weight        [2*hidden, C]*/
+    const float* pin_bias;        /* ffn.project_in.bias          [2*hidden]   */
+    const float* ffn_dw_weight;   /* ffn.dwconv.weight            [2*hidden, 9]*/
+    const float* ffn_dw_bias;     /* ffn.dwconv.bias              [2*hidden]   */
+    const float* pout_weight;     /* ffn.project_out.weight       [C, hidden]  */
+    const float* pout_bias;       /* ffn.project_out.bias         [C]          */
+} rst_block_params;
+
+/* Same layout, writable: gradients of the parameters (overwritten, not accumulated). */
+typedef struct rst_block_grads {
+    float* norm1_weight;
+    float* norm1_bias;
+    float* temperature;
+    float* qkv_weight;
+    float* qkv_bias;
+    float* qkv_dw_weight;
+    float* qkv_dw_bias;
+    float* proj_weight;
+    float* proj_bias;
+    float* norm2_weight;
+    float* norm2_bias;
+    float* pin_weight;
+    float* pin_bias;
+    float* ffn_dw_weight;
+    float* ffn_dw_bias;
+    float* pout_weight;
+    float* pout_bias;
+} rst_block_grads;
+
+/* ------------------------------------------------------------------------- */
+/* Channel LayerNorm -- replaces LayerNorm.forward, model/Restromer.py:72-74  */
+/* (to_3d/to_4d :20-25 are views; WithBias :58-61, BiasFree :40-42).          */
+/* bias == NULL selects the BiasFree flavour.  x, y: [B, C, N].               */
+/* ------------------------------------------------------------------------- */
+int rst_layernorm_fwd(const float* x, const float* weight, const float* bias, float* y,
+                      int32_t B, int32_t C, int64_t N, void* stream);
+
+/* Backward of the above (autograd of model/Restromer.py:40-42,58-61).
+ * dx is overwritten, or accumulated into when accumulate_dx != 0.
+ * dweight [C] and dbias [C] (dbias ignored when with_bias == 0) are overwritten. */
+size_t rst_layernorm_bwd_workspace_bytes(int32_t B, int32_t C, int64_t N);
+int rst_layernorm_bwd(const float* x, const float* weight, int32_t with_bias, const float* dy,
+                      float* dx, int32_t accumulate_dx, float* dweight, float* dbias,
+                      int32_t B, int32_t C, int64_t N,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* 1x1 convolution -- replaces the nn.Conv2d(kernel_size=1) calls at          */
+/* model/Restromer.py:100,103,130(qkv),149 and reduce_chan_level{3,2} :403,408.*/
+/* y[b] = W x[b] (+ bias) (+ residual[b]);  x: [B, Cin, N], y: [B, Cout, N].  */
+/* bias, residual may be NULL.                                                */
+/* ------------------------------------------------------------------------- */
+int rst_conv1x1_fwd(const float* x, const float* weight, const float* bias, const float* residual,
+                    float* y, int32_t B, int32_t Cin, int32_t Cout, int64_t N, void* stream);
+
+/* Backward: dx = W^T dy (overwritten, or accumulated when accumulate_dx != 0; may be NULL to skip),
+ * dweight [Cout, Cin] = sum_b dy[b] x[b]^T, dbias [Cout] (may be NULL). */
+size_t rst_conv1x1_bwd_workspace_bytes(int32_t B, int32_t Cin, int32_t Cout, int64_t N);
+int rst_conv1x1_bwd(const float* x, const float* weight, const float* dy,
+                    float* dx, int32_t accumulate_dx, float* dweight, float* dbias,
+                    int32_t B, int32_t Cin, int32_t Cout, int64_t N,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* Depthwise 3x3, zero padding 1 -- replaces qkv_dwconv / dwconv,             */
+/* model/Restromer.py:87-95,116-124.  x, y: [B, C, H, W]; weight: [C, 9].     */
+/* ------------------------------------------------------------------------- */
+int rst_dwconv3x3_fwd(const float* x, const float* weight, const float* bias, float* y,
+                      int32_t B, int32_t C, int32_t H, int32_t W, void* stream);
+size_t rst_dwconv3x3_bwd_workspace_bytes(int32_t B, int32_t C, int32_t H, int32_t W);
+int rst_dwconv3x3_bwd(const float* x, const float* weight, const float* dy,
+                      float* dx, float* dweight, float* dbias,
+                      int32_t B, int32_t C, int32_t H, int32_t W,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* PixelUnshuffle(2) / PixelShuffle(2) -- model/Restromer.py:196,211.         */
+/* unshuffle: [B, C, H, W] -> [B, 4C, H/2, W/2]; shuffle: [B, 4C, H, W] ->    */
+/* [B, C, 2H, 2W].  Each is the other's backward.                             */
+/* ------------------------------------------------------------------------- */
+int rst_pixel_unshuffle2(const float* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, void* stream);
+int rst_pixel_shuffle2(const float* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* MDTA -- replaces Attention.forward, model/Restromer.py:127-150.            */
+/* y = [residual +] project_out( softmax(q^ k^T * temperature) v )            */
+/* with q,k,v = split(dwconv3x3(conv1x1(x))).  Uses desc.{B,C,H,W,heads,      */
+/* conv_bias} and params.{temperature,qkv_*,proj_*}.                          */
+/* saved: NULL for inference; else a buffer of rst_attention_saved_bytes that */
+/* receives what the backward needs.                                          */
+/* ------------------------------------------------------------------------- */
+size_t rst_attention_workspace_bytes(const rst_block_desc* desc);
+size_t rst_attention_saved_bytes(const rst_block_desc* desc);
+int rst_attention_fwd(const rst_block_desc* desc, const rst_block_params* params,
+                      const float* x, const float* residual, float* y,
+                      void* saved, void* workspace, size_t workspace_bytes, void* stream);
+/* Backward: given dy, writes dx (gradient w.r.t. x only; the residual branch
+ * is the caller's) and the gradients of temperature, qkv_*, proj_*. */
+size_t rst_attention_bwd_workspace_bytes(const rst_block_desc* desc);
+int rst_attention_bwd(const rst_block_desc* desc, const rst_block_params* params,
+                      const float* x, const float* dy, const void* saved,
+                      float* dx, int32_t accumulate_dx, rst_block_grads* grads,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* GDFN -- replaces FeedForward.forward, model/Restromer.py:99-104.           */
+/* y = [residual +] project_out( gelu(d1) * d2 ),  d = dwconv3x3(project_in(x)). */
+/* ------------------------------------------------------------------------- */
+size_t rst_ffn_workspace_bytes(const rst_block_desc* desc);
+size_t rst_ffn_saved_bytes(const rst_block_desc* desc);
+int rst_ffn_fwd(const rst_block_desc* desc, const rst_block_params* params,
+                const float* x, const float* residual, float* y,
+                void* saved, void* workspace, size_t workspace_bytes, void* stream);
+size_t rst_ffn_bwd_workspace_bytes(const rst_block_desc* desc);
+int rst_ffn_bwd(const rst_block_desc* desc, const rst_block_params* params,
+                const float* x, const float* dy, const void* saved,
+                float* dx, int32_t accumulate_dx, rst_block_grads* grads,
+                void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/* TransformerBlock -- replaces TransformerBlock.forward,                     */
+/* model/Restromer.py:163-167:  x += attn(norm1(x)); x += ffn(norm2(x)).      */
+/* y may alias x only when saved == NULL.                                     */
+/* ------------------------------------------------------------------------- */
+size_t rst_block_workspace_bytes(const rst_block_desc* desc);
+size_t rst_block_saved_bytes(const rst_block_desc* desc);
+int rst_block_fwd(const rst_block_desc* desc, const rst_block_params* params,
+                  const float* x, float* y,
+                  void* saved, void* workspace, size_t workspace_bytes, void* stream);
+size_t rst_block_bwd_workspace_bytes(const rst_block_desc* desc);
+int rst_block_bwd(const rst_block_desc* desc, const rst_block_params* params,
+                  const float* x, const float* dy, const void* saved,
+                  float* dx, rst_block_grads* grads,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RESTORMER_HIP_H */

@@ -1,0 +1,615 @@
+// C ABI of the library (declared in include/restormer_hip.h): argument checks,
+// workspace carving and the launch sequences of the composite operators.
+#include "kernels.hpp"
+
+namespace rst {
+
+std::string& last_error_slot() {
+    static thread_local std::string s;
+    return s;
+}
+
+// Bump allocator over a caller-provided buffer.  With base == nullptr it only
+// measures, so the same carving code serves the *_bytes queries.
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* b) : base(static_cast<char*>(b)) {}
+    float* floats(size_t n) {
+        off = (off + 255) & ~size_t(255);
+        float* p = base ? reinterpret_cast<float*>(base + off) : nullptr;
+        off += n * sizeof(float);
+        return p;
+    }
+    void* bytes(size_t n) {
+        off = (off + 255) & ~size_t(255);
+        void* p = base ? static_cast<void*>(base + off) : nullptr;
+        off += n;
+        return p;
+    }
+    size_t total() const { return (off + 255) & ~size_t(255); }
+};
+
+static inline size_t max2(size_t a, size_t b) { return a > b ? a : b; }
+
+static int check_desc(const rst_block_desc* d) {
+    RST_REQUIRE(d != nullptr, "null block descriptor");
+    RST_REQUIRE(d->B > 0 && d->C > 0 && d->H > 0 && d->W > 0, "block: empty shape B=%d C=%d H=%d W=%d", d->B, d->C, d->H, d->W);
+    RST_REQUIRE(d->heads > 0 && d->C % d->heads == 0, "block: C=%d not divisible by heads=%d", d->C, d->heads);
+    RST_REQUIRE(d->hidden > 0, "block: hidden=%d", d->hidden);
+    RST_REQUIRE(d->B <= 65535 / d->heads, "block: batch*heads exceeds 65535");
+    return RST_OK;
+}
+
+// ---- plain 1x1 convolution helpers ---------------------------------------------
+static GemmNN conv1x1_args(const float* w, int Cout, int Cin, bool transposed, const float* x, float* y, int B, int64_t N) {
+    GemmNN g{};
+    g.A = w; g.a_s1 = 0; g.a_s2 = 0; g.transA = transposed ? 1 : 0;
+    // stored weight is [Cout][Cin]; transposed product uses it as [K=Cout][M=Cin]
+    g.lda = Cin;
+    g.M = transposed ? Cin : Cout;
+    g.K = transposed ? Cout : Cin;
+    g.X = x; g.x_s1 = (int64_t)g.K * N; g.x_s2 = 0; g.ldx = N;
+    g.Y = y; g.y_s1 = (int64_t)g.M * N; g.y_s2 = 0; g.ldy = N;
+    g.R = nullptr; g.rscale = nullptr; g.bias = nullptr;
+    g.N = N; g.nb1 = B; g.nb2 = 1; g.accumulate = 0;
+    return g;
+}
+
+// dW[M1][M2] = sum_b A[b] Bm[b]^T through split-K partials in `ws`
+static size_t wgrad_ws_floats(int M1, int M2, int64_t N, int B) {
+    const NtPlan p = gemm_nt_plan(M1, M2, N, B);
+    return gemm_nt_partial_floats(p, M1, M2, B);
+}
+static int wgrad(const float* a, int64_t a_bs, const float* bm, int64_t b_bs, int M1, int M2, int64_t N, int B,
+                 float* out, float* partial, hipStream_t stream) {
+    const NtPlan p = gemm_nt_plan(M1, M2, N, B);
+    GemmNT g{};
+    g.A = a; g.a_s1 = a_bs; g.a_s2 = 0; g.lda = N;
+    g.Bm = bm; g.b_s1 = b_bs; g.b_s2 = 0; g.ldb = N;
+    g.M1 = M1; g.M2 = M2; g.N = N; g.nb1 = B; g.nb2 = 1;
+    g.partial = partial; g.sqA_partial = nullptr; g.sqB_partial = nullptr;
+    RST_TRY(gemm_nt_launch(g, p, stream));
+    return reduce_slabs_launch(partial, out, (int64_t)M1 * M2, 1, B * p.splits, 0, stream);
+}
+
+// ================================ attention =======================================
+struct AttnBufs {
+    // kept for the backward pass (in `saved`) or scratch (in the workspace)
+    float *t, *qkv, *attn, *ghat, *nq, *nk, *mfold;
+    // scratch
+    float *gram_part, *sqq_part, *sqk_part;
+    NtPlan plan;
+};
+
+static void attn_carve_saved(const rst_block_desc* d, Carver& cv, AttnBufs& b) {
+    const int64_t N = (int64_t)d->H * d->W;
+    const int c = d->C / d->heads;
+    b.t = cv.floats((size_t)d->B * 3 * d->C * N);
+    b.qkv = cv.floats((size_t)d->B * 3 * d->C * N);
+    b.attn = cv.floats((size_t)d->B * d->heads * c * c);
+    b.ghat = cv.floats((size_t)d->B * d->heads * c * c);
+    b.nq = cv.floats((size_t)d->B * d->C);
+    b.nk = cv.floats((size_t)d->B * d->C);
+    b.mfold = cv.floats((size_t)d->B * d->C * d->C);
+}
+static void attn_carve_ws(const rst_block_desc* d, bool have_saved, Carver& cv, AttnBufs& b) {
+    const int64_t N = (int64_t)d->H * d->W;
+    const int c = d->C / d->heads;
+    const int BH = d->B * d->heads;
+    b.plan = gemm_nt_plan(c, c, N, BH);
+    b.gram_part = cv.floats(gemm_nt_partial_floats(b.plan, c, c, BH));
+    b.sqq_part = cv.floats((size_t)BH * b.plan.splits * c);
+    b.sqk_part = cv.floats((size_t)BH * b.plan.splits * c);
+    if (!have_saved) {
+        b.t = cv.floats((size_t)d->B * 3 * d->C * N);
+        b.qkv = cv.floats((size_t)d->B * 3 * d->C * N);
+        b.attn = cv.floats((size_t)BH * c * c);
+        b.mfold = cv.floats((size_t)d->B * d->C * d->C);
+        b.ghat = nullptr; b.nq = nullptr; b.nk = nullptr;
+    }
+}
+
+static size_t attention_ws_bytes(const rst_block_desc* d) {
+    Carver cv(nullptr); AttnBufs b{};
+    attn_carve_ws(d, false, cv, b);
+    return cv.total();
+}
+static size_t attention_saved_bytes(const rst_block_desc* d) {
+    Carver cv(nullptr); AttnBufs b{};
+    attn_carve_saved(d, cv, b);
+    return cv.total();
+}
+
+static int attention_fwd(const rst_block_desc* d, const rst_block_params* p, const float* x, const float* residual,
+                         float* y, void* saved, void* ws, size_t ws_bytes, hipStream_t stream) {
+    RST_REQUIRE(x && y && p, "attention_fwd: null operand");
+    RST_REQUIRE(p->temperature && p->qkv_weight && p->qkv_dw_weight && p->proj_weight, "attention_fwd: null parameter");
+    RST_REQUIRE(!d->conv_bias || (p->qkv_bias && p->qkv_dw_bias && p->proj_bias), "attention_fwd: conv_bias set but a bias is null");
+    if (ws == nullptr || ws_bytes < attention_ws_bytes(d))
+        return fail(RST_ERR_WORKSPACE, "attention_fwd: workspace %zu < %zu bytes", ws_bytes, attention_ws_bytes(d));
+    const int B = d->B, C = d->C, heads = d->heads, c = C / heads;
+    const int64_t N = (int64_t)d->H * d->W;
+    AttnBufs b{};
+    if (saved) { Carver cs(saved); attn_carve_saved(d, cs, b); }
+    Carver cw(ws);
+    attn_carve_ws(d, saved != nullptr, cw, b);
+
+    // t = W_qkv x (+bias);  qkv = dw3x3(t)
+    GemmNN g1 = conv1x1_args(p->qkv_weight, 3 * C, C, false, x, b.t, B, N);
+    g1.bias = d->conv_bias ? p->qkv_bias : nullptr;
+    RST_TRY(gemm_nn_launch(g1, stream));
+    DwArgs dw{};
+    dw.x = b.t; dw.x_bstride = (int64_t)3 * C * N; dw.w = p->qkv_dw_weight;
+    dw.bias = d->conv_bias ? p->qkv_dw_bias : nullptr;
+    dw.y = b.qkv; dw.y_bstride = (int64_t)3 * C * N; dw.B = B; dw.C = 3 * C; dw.H = d->H; dw.W = d->W; dw.flip = 0;
+    RST_TRY(dwconv_fwd_launch(dw, stream));
+
+    // Gram matrices and squared row norms, split over the pixels
+    GemmNT gt{};
+    gt.A = b.qkv;                      gt.a_s1 = (int64_t)3 * C * N; gt.a_s2 = (int64_t)c * N; gt.lda = N;
+    gt.Bm = b.qkv + (int64_t)C * N;    gt.b_s1 = (int64_t)3 * C * N; gt.b_s2 = (int64_t)c * N; gt.ldb = N;
+    gt.M1 = c; gt.M2 = c; gt.N = N; gt.nb1 = B; gt.nb2 = heads;
+    gt.partial = b.gram_part; gt.sqA_partial = b.sqq_part; gt.sqB_partial = b.sqk_part;
+    RST_TRY(gemm_nt_launch(gt, b.plan, stream));
+    RST_TRY(attn_softmax_launch(b.gram_part, b.sqq_part, b.sqk_part, p->temperature, b.attn, b.ghat, b.nq, b.nk,
+                                B, heads, c, b.plan.splits, stream));
+    RST_TRY(attn_fold_launch(p->proj_weight, b.attn, b.mfold, B, C, heads, c, stream));
+
+    // y = Mfold[b] v (+bias) (+residual)
+    GemmNN g2{};
+    g2.A = b.mfold; g2.a_s1 = (int64_t)C * C; g2.a_s2 = 0; g2.lda = C; g2.transA = 0;
+    g2.X = b.qkv + (int64_t)2 * C * N; g2.x_s1 = (int64_t)3 * C * N; g2.x_s2 = 0; g2.ldx = N;
+    g2.Y = y; g2.y_s1 = (int64_t)C * N; g2.y_s2 = 0; g2.ldy = N;
+    g2.R = residual; g2.r_s1 = (int64_t)C * N; g2.r_s2 = 0; g2.ldr = N; g2.rscale = nullptr;
+    g2.bias = d->conv_bias ? p->proj_bias : nullptr;
+    g2.M = C; g2.K = C; g2.N = N; g2.nb1 = B; g2.nb2 = 1; g2.accumulate = 0;
+    return gemm_nn_launch(g2, stream);
+}
+
+// ---- attention backward --------------------------------------------------------
+// With o = Mfold v (+bias) and dy the gradient of o:
+//   P[b]   = dy[b] v[b]^T                    (C x C, split-K over the pixels)
+//   dWo    = sum_b P[b] blockdiag(A[b])^T ;  dA[b,h] = (Wo^T P[b])_hh
+//   softmax / temperature / normalisation on c x c matrices (attn_small.hip)
+//   dq_h = Eq k_h + Dq o q_h ;  dk_h = Eq^T q_h + Dk o k_h ;  dv = Mfold^T dy
+//   then the depthwise and the 1x1 convolution backwards.
+struct AttnBwdBufs {
+    float *P, *P_part, *Eq, *Dq, *Dk, *dGG, *dtemp_row, *dtemp_b, *dwo_b, *dqkv, *dt, *wg_part, *dwws, *rsws;
+    NtPlan p_plan;
+    size_t dwws_bytes, rsws_bytes;
+};
+static void attn_bwd_carve(const rst_block_desc* d, Carver& cv, AttnBwdBufs& b) {
+    const int B = d->B, C = d->C, heads = d->heads, c = C / heads;
+    const int64_t N = (int64_t)d->H * d->W;
+    b.p_plan = gemm_nt_plan(C, C, N, B);
+    b.P = cv.floats((size_t)B * C * C);
+    b.P_part = cv.floats(gemm_nt_partial_floats(b.p_plan, C, C, B));
+    b.Eq = cv.floats((size_t)B * heads * c * c);
+    b.Dq = cv.floats((size_t)B * C);
+    b.Dk = cv.floats((size_t)B * C);
+    b.dGG = cv.floats((size_t)B * heads * c * c);
+    b.dtemp_row = cv.floats((size_t)B * C);
+    b.dtemp_b = cv.floats((size_t)B * heads);
+    b.dwo_b = cv.floats((size_t)B * C * C);
+    b.dqkv = cv.floats((size_t)B * 3 * C * N);
+    b.dt = cv.floats((size_t)B * 3 * C * N);
+    b.wg_part = cv.floats(wgrad_ws_floats(3 * C, C, N, B));
+    b.dwws_bytes = dwconv_bwd_weight_ws_bytes(B, 3 * C, d->H, d->W);
+    b.dwws = static_cast<float*>(cv.bytes(b.dwws_bytes));
+    b.rsws_bytes = rowsum_ws_bytes(B, 3 * C, N);
+    b.rsws = static_cast<float*>(cv.bytes(b.rsws_bytes));
+}
+static size_t attention_bwd_ws_bytes(const rst_block_desc* d) {
+    Carver cv(nullptr); AttnBwdBufs b{};
+    attn_bwd_carve(d, cv, b);
+    return cv.total();
+}
+
+static int attention_bwd(const rst_block_desc* d, const rst_block_params* p, const float* x, const float* dy,
+                         const void* saved, float* dx, int accumulate_dx, rst_block_grads* gr,
+                         void* ws, size_t ws_bytes, hipStream_t stream) {
+    RST_REQUIRE(x && dy && saved && dx && gr && p, "attention_bwd: null operand");
+    RST_REQUIRE(gr->temperature && gr->qkv_weight && gr->qkv_dw_weight && gr->proj_weight, "attention_bwd: null gradient buffer");
+    RST_REQUIRE(!d->conv_bias || (gr->qkv_bias && gr->qkv_dw_bias && gr->proj_bias), "attention_bwd: null bias gradient buffer");
+    if (ws == nullptr || ws_bytes < attention_bwd_ws_bytes(d))
+        return fail(RST_ERR_WORKSPACE, "attention_bwd: workspace %zu < %zu bytes", ws_bytes, attention_bwd_ws_bytes(d));
+    const int B = d->B, C = d->C, heads = d->heads, c = C / heads;
+    const int64_t N = (int64_t)d->H * d->W;
+    AttnBufs s{};
+    { Carver cs(const_cast<void*>(saved)); attn_carve_saved(d, cs, s); }
+    AttnBwdBufs b{};
+    { Carver cw(ws); attn_bwd_carve(d, cw, b); }
+    const float* q = s.qkv;
+    const float* k = s.qkv + (int64_t)C * N;
+    const float* v = s.qkv + (int64_t)2 * C * N;
+    const int64_t qs = (int64_t)3 * C * N;
+
+    // P[b] = dy[b] v[b]^T
+    {
+        GemmNT g{};
+        g.A = dy; g.a_s1 = (int64_t)C * N; g.a_s2 = 0; g.lda = N;
+        g.Bm = v; g.b_s1 = qs; g.b_s2 = 0; g.ldb = N;
+        g.M1 = C; g.M2 = C; g.N = N; g.nb1 = B; g.nb2 = 1;
+        g.partial = b.P_part;
+        RST_TRY(gemm_nt_launch(g, b.p_plan, stream));
+        RST_TRY(reduce_slabs_launch(b.P_part, b.P, (int64_t)C * C, B, b.p_plan.splits, 0, stream));
+    }
+    if (d->conv_bias) RST_TRY(rowsum_launch(dy, (int64_t)C * N, gr->proj_bias, B, C, N, b.rsws, b.rsws_bytes, stream));
+    RST_TRY(attn_bwd_small_launch(b.P, p->proj_weight, s.attn, s.ghat, s.nq, s.nk, p->temperature, b.Eq, b.Dq, b.Dk,
+                                  b.dGG, b.dtemp_row, b.dtemp_b, b.dwo_b, B, C, heads, c, stream));
+    RST_TRY(reduce_slabs_launch(b.dwo_b, gr->proj_weight, (int64_t)C * C, 1, B, 0, stream));
+    RST_TRY(reduce_slabs_launch(b.dtemp_b, gr->temperature, heads, 1, B, 0, stream));
+
+    // dq, dk per (sample, head); dv per sample
+    {
+        GemmNN g{};
+        g.A = b.Eq; g.a_s1 = (int64_t)heads * c * c; g.a_s2 = (int64_t)c * c; g.lda = c; g.transA = 0;
+        g.X = k; g.x_s1 = qs; g.x_s2 = (int64_t)c * N; g.ldx = N;
+        g.Y = b.dqkv; g.y_s1 = qs; g.y_s2 = (int64_t)c * N; g.ldy = N;
+        g.R = q; g.r_s1 = qs; g.r_s2 = (int64_t)c * N; g.ldr = N;
+        g.rscale = b.Dq; g.rs_s1 = C; g.rs_s2 = c;
+        g.bias = nullptr; g.M = c; g.K = c; g.N = N; g.nb1 = B; g.nb2 = heads; g.accumulate = 0;
+        RST_TRY(gemm_nn_launch(g, stream));
+        g.transA = 1;
+        g.X = q; g.Y = b.dqkv + (int64_t)C * N; g.R = k; g.rscale = b.Dk;
+        RST_TRY(gemm_nn_launch(g, stream));
+    }
+    {
+        GemmNN g{};
+        g.A = s.mfold; g.a_s1 = (int64_t)C * C; g.a_s2 = 0; g.lda = C; g.transA = 1;
+        g.X = dy; g.x_s1 = (int64_t)C * N; g.x_s2 = 0; g.ldx = N;
+        g.Y = b.dqkv + (int64_t)2 * C * N; g.y_s1 = qs; g.y_s2 = 0; g.ldy = N;
+        g.R = nullptr; g.rscale = nullptr; g.bias = nullptr;
+        g.M = C; g.K = C; g.N = N; g.nb1 = B; g.nb2 = 1; g.accumulate = 0;
+        RST_TRY(gemm_nn_launch(g, stream));
+    }
+    // depthwise conv backward
+    RST_TRY(dwconv_bwd_weight_launch(s.t, qs, b.dqkv, qs, gr->qkv_dw_weight, d->conv_bias ? gr->qkv_dw_bias : nullptr,
+                                     B, 3 * C, d->H, d->W, b.dwws, b.dwws_bytes, stream));
+    {
+        DwArgs dw{};
+        dw.x = b.dqkv; dw.x_bstride = qs; dw.w = p->qkv_dw_weight; dw.bias = nullptr;
+        dw.y = b.dt; dw.y_bstride = qs; dw.B = B; dw.C = 3 * C; dw.H = d->H; dw.W = d->W; dw.flip = 1;
+        RST_TRY(dwconv_fwd_launch(dw, stream));
+    }
+    // 1x1 qkv conv backward
+    RST_TRY(wgrad(b.dt, qs, x, (int64_t)C * N, 3 * C, C, N, B, gr->qkv_weight, b.wg_part, stream));
+    if (d->conv_bias) RST_TRY(rowsum_launch(b.dt, qs, gr->qkv_bias, B, 3 * C, N, b.rsws, b.rsws_bytes, stream));
+    GemmNN gx = conv1x1_args(p->qkv_weight, 3 * C, C, true, b.dt, dx, B, N);
+    gx.accumulate = accumulate_dx;
+    return gemm_nn_launch(gx, stream);
+}
+
+// ================================== GDFN ===========================================
+struct FfnBufs { float *u, *d, *g; };
+static void ffn_carve(const rst_block_desc* d, bool with_d, Carver& cv, FfnBufs& b) {
+    const int64_t N = (int64_t)d->H * d->W;
+    b.u = cv.floats((size_t)d->B * 2 * d->hidden * N);
+    b.d = with_d ? cv.floats((size_t)d->B * 2 * d->hidden * N) : nullptr;
+    b.g = cv.floats((size_t)d->B * d->hidden * N);
+}
+static size_t ffn_ws_bytes(const rst_block_desc* d) {
+    Carver cv(nullptr); FfnBufs b{};
+    ffn_carve(d, false, cv, b);
+    return cv.total();
+}
+static size_t ffn_saved_bytes(const rst_block_desc* d) {
+    Carver cv(nullptr); FfnBufs b{};
+    ffn_carve(d, true, cv, b);
+    return cv.total();
+}
+
+static int ffn_fwd(const rst_block_desc* d, const rst_block_params* p, const float* x, const float* residual, float* y,
+                   void* saved, void* ws, size_t ws_bytes, hipStream_t stream) {
+    RST_REQUIRE(x && y && p, "ffn_fwd: null operand");
+    RST_REQUIRE(p->pin_weight && p->ffn_dw_weight && p->pout_weight, "ffn_fwd: null parameter");
+    RST_REQUIRE(!d->conv_bias || (p->pin_bias && p->ffn_dw_bias && p->pout_bias), "ffn_fwd: conv_bias set but a bias is null");
+    FfnBufs b{};
+    if (saved) {
+        Carver cs(saved); ffn_carve(d, true, cs, b);
+    } else {
+        if (ws == nullptr || ws_bytes < ffn_ws_bytes(d))
+            return fail(RST_ERR_WORKSPACE, "ffn_fwd: workspace %zu < %zu bytes", ws_bytes, ffn_ws_bytes(d));
+        Carver cw(ws); ffn_carve(d, false, cw, b);
+    }
+    const int B = d->B, C = d->C, Hd = d->hidden;
+    const int64_t N = (int64_t)d->H * d->W;
+    GemmNN g1 = conv1x1_args(p->pin_weight, 2 * Hd, C, false, x, b.u, B, N);
+    g1.bias = d->conv_bias ? p->pin_bias : nullptr;
+    RST_TRY(gemm_nn_launch(g1, stream));
+    GateArgs ga{};
+    ga.u = b.u; ga.u_bstride = (int64_t)2 * Hd * N; ga.w = p->ffn_dw_weight; ga.bias = d->conv_bias ? p->ffn_dw_bias : nullptr;
+    ga.gout = b.g; ga.g_bstride = (int64_t)Hd * N; ga.d = b.d; ga.d_bstride = (int64_t)2 * Hd * N;
+    ga.B = B; ga.hidden = Hd; ga.H = d->H; ga.W = d->W;
+    RST_TRY(dwconv_gate_fwd_launch(ga, stream));
+    GemmNN g2 = conv1x1_args(p->pout_weight, C, Hd, false, b.g, y, B, N);
+    g2.bias = d->conv_bias ? p->pout_bias : nullptr;
+    g2.R = residual; g2.r_s1 = (int64_t)C * N; g2.r_s2 = 0; g2.ldr = N;
+    return gemm_nn_launch(g2, stream);
+}
+
+struct FfnBwdBufs { float *dg, *dd, *du, *wg_part, *dwws, *rsws; size_t dwws_bytes, rsws_bytes; };
+static void ffn_bwd_carve(const rst_block_desc* d, Carver& cv, FfnBwdBufs& b) {
+    const int B = d->B, C = d->C, Hd = d->hidden;
+    const int64_t N = (int64_t)d->H * d->W;
+    b.dg = cv.floats((size_t)B * Hd * N);
+    b.dd = cv.floats((size_t)B * 2 * Hd * N);
+    b.du = cv.floats((size_t)B * 2 * Hd * N);
+    b.wg_part = cv.floats(max2(wgrad_ws_floats(C, Hd, N, B), wgrad_ws_floats(2 * Hd, C, N, B)));
+    b.dwws_bytes = dwconv_bwd_weight_ws_bytes(B, 2 * Hd, d->H, d->W);
+    b.dwws = static_cast<float*>(cv.bytes(b.dwws_bytes));
+    b.rsws_bytes = rowsum_ws_bytes(B, max2(2 * Hd, C), N);
+    b.rsws = static_cast<float*>(cv.bytes(b.rsws_bytes));
+}
+static size_t ffn_bwd_ws_bytes(const rst_block_desc* d) {
+    Carver cv(nullptr); FfnBwdBufs b{};
+    ffn_bwd_carve(d, cv, b);
+    return cv.total();
+}
+
+static int ffn_bwd(const rst_block_desc* d, const rst_block_params* p, const float* x, const float* dy, const void* saved,
+                   float* dx, int accumulate_dx, rst_block_grads* gr, void* ws, size_t ws_bytes, hipStream_t stream) {
+    RST_REQUIRE(x && dy && saved && dx && gr && p, "ffn_bwd: null operand");
+    RST_REQUIRE(gr->pin_weight && gr->ffn_dw_weight && gr->pout_weight, "ffn_bwd: null gradient buffer");
+    RST_REQUIRE(!d->conv_bias || (gr->pin_bias && gr->ffn_dw_bias && gr->pout_bias), "ffn_bwd: null bias gradient buffer");
+    if (ws == nullptr || ws_bytes < ffn_bwd_ws_bytes(d))
+        return fail(RST_ERR_WORKSPACE, "ffn_bwd: workspace %zu < %zu bytes", ws_bytes, ffn_bwd_ws_bytes(d));
+    const int B = d->B, C = d->C, Hd = d->hidden;
+    const int64_t N = (int64_t)d->H * d->W;
+    FfnBufs s{};
+    { Carver cs(const_cast<void*>(saved)); ffn_carve(d, true, cs, s); }
+    FfnBwdBufs b{};
+    { Carver cw(ws); ffn_bwd_carve(d, cw, b); }
+
+    // project_out: dW = sum dy g^T, dg = W^T dy
+    RST_TRY(wgrad(dy, (int64_t)C * N, s.g, (int64_t)Hd * N, C, Hd, N, B, gr->pout_weight, b.wg_part, stream));
+    if (d->conv_bias) RST_TRY(rowsum_launch(dy, (int64_t)C * N, gr->pout_bias, B, C, N, b.rsws, b.rsws_bytes, stream));
+    GemmNN g1 = conv1x1_args(p->pout_weight, C, Hd, true, dy, b.dg, B, N);
+    RST_TRY(gemm_nn_launch(g1, stream));
+    // gate and depthwise conv
+    RST_TRY(gate_bwd_launch(b.dg, s.d, b.dd, B, Hd, N, stream));
+    RST_TRY(dwconv_bwd_weight_launch(s.u, (int64_t)2 * Hd * N, b.dd, (int64_t)2 * Hd * N, gr->ffn_dw_weight,
+                                     d->conv_bias ? gr->ffn_dw_bias : nullptr, B, 2 * Hd, d->H, d->W, b.dwws, b.dwws_bytes, stream));
+    DwArgs dw{};
+    dw.x = b.dd; dw.x_bstride = (int64_t)2 * Hd * N; dw.w = p->ffn_dw_weight; dw.bias = nullptr;
+    dw.y = b.du; dw.y_bstride = (int64_t)2 * Hd * N; dw.B = B; dw.C = 2 * Hd; dw.H = d->H; dw.W = d->W; dw.flip = 1;
+    RST_TRY(dwconv_fwd_launch(dw, stream));
+    // project_in
+    RST_TRY(wgrad(b.du, (int64_t)2 * Hd * N, x, (int64_t)C * N, 2 * Hd, C, N, B, gr->pin_weight, b.wg_part, stream));
+    if (d->conv_bias) RST_TRY(rowsum_launch(b.du, (int64_t)2 * Hd * N, gr->pin_bias, B, 2 * Hd, N, b.rsws, b.rsws_bytes, stream));
+    GemmNN gx = conv1x1_args(p->pin_weight, 2 * Hd, C, true, b.du, dx, B, N);
+    gx.accumulate = accumulate_dx;
+    return gemm_nn_launch(gx, stream);
+}
+
+// ================================== block ==========================================
+struct BlockSaved { float *xn1, *x1, *xn2; void *attn, *ffn; };
+static void block_carve_saved(const rst_block_desc* d, Carver& cv, BlockSaved& s) {
+    const size_t n = (size_t)d->B * d->C * d->H * d->W;
+    s.xn1 = cv.floats(n);
+    s.x1 = cv.floats(n);
+    s.xn2 = cv.floats(n);
+    s.attn = cv.bytes(attention_saved_bytes(d));
+    s.ffn = cv.bytes(ffn_saved_bytes(d));
+}
+static size_t block_saved_bytes(const rst_block_desc* d) {
+    Carver cv(nullptr); BlockSaved s{};
+    block_carve_saved(d, cv, s);
+    return cv.total();
+}
+static size_t block_ws_bytes(const rst_block_desc* d) {
+    // xn (shared by both norms) + the larger of the two sub-operator workspaces
+    Carver cv(nullptr);
+    cv.floats((size_t)d->B * d->C * d->H * d->W);
+    cv.bytes(max2(attention_ws_bytes(d), ffn_ws_bytes(d)));
+    return cv.total();
+}
+
+static int block_fwd(const rst_block_desc* d, const rst_block_params* p, const float* x, float* y, void* saved,
+                     void* ws, size_t ws_bytes, hipStream_t stream) {
+    RST_REQUIRE(x && y && p, "block_fwd: null operand");
+    RST_REQUIRE(p->norm1_weight && p->norm2_weight, "block_fwd: null LayerNorm weight");
+    RST_REQUIRE(!d->ln_with_bias || (p->norm1_bias && p->norm2_bias), "block_fwd: ln_with_bias set but a bias is null");
+    RST_REQUIRE(!(saved && x == y), "block_fwd: in-place update is only allowed without a saved buffer");
+    if (ws == nullptr || ws_bytes < block_ws_bytes(d))
+        return fail(RST_ERR_WORKSPACE, "block_fwd: workspace %zu < %zu bytes", ws_bytes, block_ws_bytes(d));
+    const int B = d->B, C = d->C;
+    const int64_t N = (int64_t)d->H * d->W;
+    Carver cw(ws);
+    float* xn = cw.floats((size_t)B * C * N);
+    const size_t sub_bytes = max2(attention_ws_bytes(d), ffn_ws_bytes(d));
+    void* sub = cw.bytes(sub_bytes);
+    BlockSaved s{};
+    float* xn1 = xn; float* xn2 = xn; float* x1 = y;
+    if (saved) {
+        Carver cs(saved); block_carve_saved(d, cs, s);
+        xn1 = s.xn1; xn2 = s.xn2; x1 = s.x1;
+    }
+    RST_TRY(layernorm_fwd_launch(x, p->norm1_weight, d->ln_with_bias ? p->norm1_bias : nullptr, xn1, B, C, N, stream));
+    RST_TRY(attention_fwd(d, p, xn1, x, x1, s.attn, sub, sub_bytes, stream));
+    RST_TRY(layernorm_fwd_launch(x1, p->norm2_weight, d->ln_with_bias ? p->norm2_bias : nullptr, xn2, B, C, N, stream));
+    return ffn_fwd(d, p, xn2, x1, y, s.ffn, sub, sub_bytes, stream);
+}
+
+static size_t block_bwd_ws_bytes(const rst_block_desc* d) {
+    Carver cv(nullptr);
+    const size_t n = (size_t)d->B * d->C * d->H * d->W;
+    cv.floats(n);   // dxn (shared)
+    cv.floats(n);   // dx1
+    cv.bytes(layernorm_bwd_ws_bytes(d->B, d->C, (int64_t)d->H * d->W));
+    cv.bytes(max2(attention_bwd_ws_bytes(d), ffn_bwd_ws_bytes(d)));
+    return cv.total();
+}
+
+static int block_bwd(const rst_block_desc* d, const rst_block_params* p, const float* x, const float* dy, const void* saved,
+                     float* dx, rst_block_grads* gr, void* ws, size_t ws_bytes, hipStream_t stream) {
+    RST_REQUIRE(x && dy && saved && dx && gr && p, "block_bwd: null operand");
+    RST_REQUIRE(gr->norm1_weight && gr->norm2_weight, "block_bwd: null LayerNorm gradient buffer");
+    RST_REQUIRE(!d->ln_with_bias || (gr->norm1_bias && gr->norm2_bias), "block_bwd: null LayerNorm bias gradient buffer");
+    if (ws == nullptr || ws_bytes < block_bwd_ws_bytes(d))
+        return fail(RST_ERR_WORKSPACE, "block_bwd: workspace %zu < %zu bytes", ws_bytes, block_bwd_ws_bytes(d));
+    const int B = d->B, C = d->C;
+    const int64_t N = (int64_t)d->H * d->W;
+    const size_t n = (size_t)B * C * N;
+    Carver cw(ws);
+    float* dxn = cw.floats(n);
+    float* dx1 = cw.floats(n);
+    const size_t ln_bytes = layernorm_bwd_ws_bytes(B, C, N);
+    void* lnws = cw.bytes(ln_bytes);
+    const size_t sub_bytes = max2(attention_bwd_ws_bytes(d), ffn_bwd_ws_bytes(d));
+    void* sub = cw.bytes(sub_bytes);
+    BlockSaved s{};
+    { Carver cs(const_cast<void*>(saved)); block_carve_saved(d, cs, s); }
+
+    // y = x1 + ffn(LN2(x1))
+    RST_TRY(ffn_bwd(d, p, s.xn2, dy, s.ffn, dxn, 0, gr, sub, sub_bytes, stream));
+    RST_TRY(layernorm_bwd_launch(s.x1, p->norm2_weight, d->ln_with_bias, dxn, dy, dx1, gr->norm2_weight, gr->norm2_bias,
+                                 B, C, N, lnws, ln_bytes, stream));
+    // x1 = x + attn(LN1(x))
+    RST_TRY(attention_bwd(d, p, s.xn1, dx1, s.attn, dxn, 0, gr, sub, sub_bytes, stream));
+    return layernorm_bwd_launch(x, p->norm1_weight, d->ln_with_bias, dxn, dx1, dx, gr->norm1_weight, gr->norm1_bias,
+                                B, C, N, lnws, ln_bytes, stream);
+}
+
+}  // namespace rst
+
+// ====================================== C ABI ========================================
+using namespace rst;
+
+extern "C" {
+
+int rst_version(void) { return 1; }
+const char* rst_last_error(void) { return last_error_slot().c_str(); }
+
+int rst_layernorm_fwd(const float* x, const float* weight, const float* bias, float* y,
+                      int32_t B, int32_t C, int64_t N, void* stream) {
+    RST_REQUIRE(x && weight && y, "layernorm_fwd: null operand");
+    RST_REQUIRE(B > 0 && C > 0 && N > 0, "layernorm_fwd: empty shape B=%d C=%d N=%lld", B, C, (long long)N);
+    return layernorm_fwd_launch(x, weight, bias, y, B, C, N, static_cast<hipStream_t>(stream));
+}
+size_t rst_layernorm_bwd_workspace_bytes(int32_t B, int32_t C, int64_t N) { return layernorm_bwd_ws_bytes(B, C, N); }
+int rst_layernorm_bwd(const float* x, const float* weight, int32_t with_bias, const float* dy,
+                      float* dx, int32_t accumulate_dx, float* dweight, float* dbias,
+                      int32_t B, int32_t C, int64_t N, void* workspace, size_t workspace_bytes, void* stream) {
+    RST_REQUIRE(x && weight && dy && dx && dweight, "layernorm_bwd: null operand");
+    RST_REQUIRE(!with_bias || dbias, "layernorm_bwd: with_bias set but dbias is null");
+    RST_REQUIRE(B > 0 && C > 0 && N > 0, "layernorm_bwd: empty shape");
+    return layernorm_bwd_launch(x, weight, with_bias, dy, accumulate_dx ? dx : nullptr, dx, dweight, dbias, B, C, N,
+                                workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int rst_conv1x1_fwd(const float* x, const float* weight, const float* bias, const float* residual, float* y,
+                    int32_t B, int32_t Cin, int32_t Cout, int64_t N, void* stream) {
+    RST_REQUIRE(x && weight && y, "conv1x1_fwd: null operand");
+    RST_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && N > 0, "conv1x1_fwd: empty shape");
+    GemmNN g = conv1x1_args(weight, Cout, Cin, false, x, y, B, N);
+    g.bias = bias;
+    g.R = residual; g.r_s1 = (int64_t)Cout * N; g.r_s2 = 0; g.ldr = N;
+    return gemm_nn_launch(g, static_cast<hipStream_t>(stream));
+}
+size_t rst_conv1x1_bwd_workspace_bytes(int32_t B, int32_t Cin, int32_t Cout, int64_t N) {
+    Carver cv(nullptr);
+    cv.floats(wgrad_ws_floats(Cout, Cin, N, B));
+    cv.bytes(rowsum_ws_bytes(B, Cout, N));
+    return cv.total();
+}
+int rst_conv1x1_bwd(const float* x, const float* weight, const float* dy, float* dx, int32_t accumulate_dx,
+                    float* dweight, float* dbias, int32_t B, int32_t Cin, int32_t Cout, int64_t N,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+    RST_REQUIRE(x && weight && dy && dweight, "conv1x1_bwd: null operand");
+    RST_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && N > 0, "conv1x1_bwd: empty shape");
+    if (workspace == nullptr || workspace_bytes < rst_conv1x1_bwd_workspace_bytes(B, Cin, Cout, N))
+        return fail(RST_ERR_WORKSPACE, "conv1x1_bwd: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    Carver cw(workspace);
+    float* part = cw.floats(wgrad_ws_floats(Cout, Cin, N, B));
+    const size_t rs_bytes = rowsum_ws_bytes(B, Cout, N);
+    void* rs = cw.bytes(rs_bytes);
+    RST_TRY(wgrad(dy, (int64_t)Cout * N, x, (int64_t)Cin * N, Cout, Cin, N, B, dweight, part, st));
+    if (dbias) RST_TRY(rowsum_launch(dy, (int64_t)Cout * N, dbias, B, Cout, N, rs, rs_bytes, st));
+    if (dx) {
+        GemmNN g = conv1x1_args(weight, Cout, Cin, true, dy, dx, B, N);
+        g.accumulate = accumulate_dx;
+        RST_TRY(gemm_nn_launch(g, st));
+    }
+    return RST_OK;
+}
+
+int rst_dwconv3x3_fwd(const float* x, const float* weight, const float* bias, float* y,
+                      int32_t B, int32_t C, int32_t H, int32_t W, void* stream) {
+    DwArgs a{};
+    a.x = x; a.x_bstride = (int64_t)C * H * W; a.w = weight; a.bias = bias;
+    a.y = y; a.y_bstride = (int64_t)C * H * W; a.B = B; a.C = C; a.H = H; a.W = W; a.flip = 0;
+    return dwconv_fwd_launch(a, static_cast<hipStream_t>(stream));
+}
+size_t rst_dwconv3x3_bwd_workspace_bytes(int32_t B, int32_t C, int32_t H, int32_t W) {
+    return dwconv_bwd_weight_ws_bytes(B, C, H, W);
+}
+int rst_dwconv3x3_bwd(const float* x, const float* weight, const float* dy, float* dx, float* dweight, float* dbias,
+                      int32_t B, int32_t C, int32_t H, int32_t W, void* workspace, size_t workspace_bytes, void* stream) {
+    RST_REQUIRE(x && weight && dy && dweight, "dwconv3x3_bwd: null operand");
+    RST_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "dwconv3x3_bwd: empty shape");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t bs = (int64_t)C * H * W;
+    RST_TRY(dwconv_bwd_weight_launch(x, bs, dy, bs, dweight, dbias, B, C, H, W, workspace, workspace_bytes, st));
+    if (dx) {
+        DwArgs a{};
+        a.x = dy; a.x_bstride = bs; a.w = weight; a.bias = nullptr; a.y = dx; a.y_bstride = bs;
+        a.B = B; a.C = C; a.H = H; a.W = W; a.flip = 1;
+        RST_TRY(dwconv_fwd_launch(a, st));
+    }
+    return RST_OK;
+}
+
+int rst_pixel_unshuffle2(const float* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, void* stream) {
+    RST_REQUIRE(H % 2 == 0 && W % 2 == 0, "pixel_unshuffle: H=%d W=%d must be even", H, W);
+    return pixel_shuffle2_launch(false, x, y, B, C, H / 2, W / 2, static_cast<hipStream_t>(stream));
+}
+int rst_pixel_shuffle2(const float* x, float* y, int32_t B, int32_t C, int32_t H, int32_t W, void* stream) {
+    return pixel_shuffle2_launch(true, x, y, B, C, H, W, static_cast<hipStream_t>(stream));
+}
+
+size_t rst_attention_workspace_bytes(const rst_block_desc* d) { return check_desc(d) == RST_OK ? attention_ws_bytes(d) : 0; }
+size_t rst_attention_saved_bytes(const rst_block_desc* d) { return check_desc(d) == RST_OK ? attention_saved_bytes(d) : 0; }
+int rst_attention_fwd(const rst_block_desc* d, const rst_block_params* p, const float* x, const float* residual, float* y,
+                      void* saved, void* workspace, size_t workspace_bytes, void* stream) {
+    RST_TRY(check_desc(d));
+    return attention_fwd(d, p, x, residual, y, saved, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+size_t rst_attention_bwd_workspace_bytes(const rst_block_desc* d) { return check_desc(d) == RST_OK ? attention_bwd_ws_bytes(d) : 0; }
+int rst_attention_bwd(const rst_block_desc* d, const rst_block_params* p, const float* x, const float* dy, const void* saved,
+                      float* dx, int32_t accumulate_dx, rst_block_grads* grads, void* workspace, size_t workspace_bytes, void* stream) {
+    RST_TRY(check_desc(d));
+    return attention_bwd(d, p, x, dy, saved, dx, accumulate_dx, grads, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+size_t rst_ffn_workspace_bytes(const rst_block_desc* d) { return check_desc(d) == RST_OK ? ffn_ws_bytes(d) : 0; }
+size_t rst_ffn_saved_bytes(const rst_block_desc* d) { return check_desc(d) == RST_OK ? ffn_saved_bytes(d) : 0; }
+int rst_ffn_fwd(const rst_block_desc* d, const rst_block_params* p, const float* x, const float* residual, float* y,
+                void* saved, void* workspace, size_t workspace_bytes, void* stream) {
+    RST_TRY(check_desc(d));
+    return ffn_fwd(d, p, x, residual, y, saved, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+size_t rst_ffn_bwd_workspace_bytes(const rst_block_desc* d) { return check_desc(d) == RST_OK ? ffn_bwd_ws_bytes(d) : 0; }
+int rst_ffn_bwd(const rst_block_desc* d, const rst_block_params* p, const float* x, const float* dy, const void* saved,
+                float* dx, int32_t accumulate_dx, rst_block_grads* grads, void* workspace, size_t workspace_bytes, void* stream) {
+    RST_TRY(check_desc(d));
+    return ffn_bwd(d, p, x, dy, saved, dx, accumulate_dx, grads, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+size_t rst_block_workspace_bytes(const rst_block_desc* d) { return check_desc(d) == RST_OK ? block_ws_bytes(d) : 0; }
+size_t rst_block_saved_bytes(const rst_block_desc* d) { return check_desc(d) == RST_OK ? block_saved_bytes(d) : 0; }
+int rst_block_fwd(const rst_block_desc* d, const rst_block_params* p, const float* x, float* y, void* saved,
+                  void* workspace, size_t workspace_bytes, void* stream) {
+    RST_TRY(check_desc(d));
+    return block_fwd(d, p, x, y, saved, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+size_t rst_block_bwd_workspace_bytes(const rst_block_desc* d) { return check_desc(d) == RST_OK ? block_bwd_ws_bytes(d) : 0; }
+int rst_block_bwd(const rst_block_desc* d, const rst_block_params* p, const float* x, const float* dy, const void* saved,
+                  float* dx, rst_block_grads* grads, void* workspace, size_t workspace_bytes, void* stream) {
+    RST_TRY(check_desc(d));
+    return block_bwd(d, p, x, dy, saved, dx, grads, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,249 @@
+// The c x c side of MDTA (model/Restromer.py:137-149): everything that happens
+// between the two sweeps over the image works on (sample, head) matrices of at
+// most a few hundred rows.
+//
+// forward:
+//   G = sum of Gram slabs, nq/nk = clamped row norms  (F.normalize folds into a
+//   rank-1 rescale of the raw Gram matrix: <q_i/|q_i|, k_j/|k_j|> = G_ij/(|q_i||k_j|))
+//   Ghat = G / (nq nk^T);  A = softmax_j(Ghat * temperature)
+//   Mfold[b] = W_o * blockdiag_h(A[b,h])   (project_out folded into attn.v)
+// backward (see attention_bwd in api.hip for the derivation):
+//   dA = (W_o^T P)_hh, dS = A o (dA - rowsum(dA o A)), dtemp, dGhat, the
+//   matrices that turn q,k into dq,dk, and dW_o.
+#include "kernels.hpp"
+
+namespace rst {
+
+constexpr float NORM_EPS = 1e-12f;
+
+// One wave per row i of one (b,h).  grid = (ceil(c/4), B*heads), block = 256.
+__global__ void __launch_bounds__(256)
+attn_softmax_kernel(const float* __restrict__ gram_partial,   // [BH][splits][c][c]
+                    const float* __restrict__ sqq_partial,    // [BH][splits][c]
+                    const float* __restrict__ sqk_partial,    // [BH][splits][c]
+                    const float* __restrict__ temperature,    // [heads]
+                    float* __restrict__ attn,                 // [BH][c][c]
+                    float* __restrict__ ghat,                 // [BH][c][c] or null
+                    float* __restrict__ nq_out,               // [BH][c] or null (clamped norms)
+                    float* __restrict__ nk_out,               // [BH][c] or null
+                    int heads, int c, int splits) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // nk[c] + 4 rows x c
+    float* nk = smem;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int bh = blockIdx.y;
+    const int h = bh % heads;
+    for (int j = tid; j < c; j += 256) {
+        float s = 0.f;
+        for (int sp = 0; sp < splits; ++sp) s += sqk_partial[((int64_t)bh * splits + sp) * c + j];
+        const float n = fmaxf(sqrtf(s), NORM_EPS);
+        nk[j] = n;
+        if (nk_out != nullptr && blockIdx.x == 0) nk_out[(int64_t)bh * c + j] = n;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= c) return;
+    float sq = 0.f;
+    for (int sp = 0; sp < splits; ++sp) sq += sqq_partial[((int64_t)bh * splits + sp) * c + i];
+    const float nq = fmaxf(sqrtf(sq), NORM_EPS);
+    if (nq_out != nullptr && lane == 0) nq_out[(int64_t)bh * c + i] = nq;
+    const float temp = temperature[h];
+    float* row = smem + c + wave * c;
+    float mx = -INFINITY;
+    for (int j = lane; j < c; j += 64) {
+        float g = 0.f;
+        for (int sp = 0; sp < splits; ++sp) g += gram_partial[(((int64_t)bh * splits + sp) * c + i) * c + j];
+        const float gh = g / (nq * nk[j]);
+        if (ghat != nullptr) ghat[((int64_t)bh * c + i) * c + j] = gh;
+        const float l = gh * temp;
+        row[j] = l;
+        mx = fmaxf(mx, l);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+    float sum = 0.f;
+    for (int j = lane; j < c; j += 64) {
+        const float e = expf(row[j] - mx);
+        row[j] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int j = lane; j < c; j += 64) attn[((int64_t)bh * c + i) * c + j] = row[j] * inv;
+}
+
+// Mfold[b][m][h*c + j] = sum_i Wo[m][h*c + i] * A[b,h][i][j]
+// grid = (ceil(C/16), heads, B), block = 256: 16 rows m x c columns j.
+__global__ void __launch_bounds__(256)
+attn_fold_kernel(const float* __restrict__ wo,      // [C][C]
+                 const float* __restrict__ attn,    // [B*heads][c][c]
+                 float* __restrict__ mfold,         // [B][C][C]
+                 int C, int heads, int c) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // A: c*c, W: 16*c
+    float* As = smem;
+    float* Ws = smem + c * c;
+    const int tid = threadIdx.x;
+    const int m0 = blockIdx.x * 16, h = blockIdx.y, b = blockIdx.z;
+    const float* Abh = attn + ((int64_t)b * heads + h) * c * c;
+    for (int e = tid; e < c * c; e += 256) As[e] = Abh[e];
+    for (int e = tid; e < 16 * c; e += 256) {
+        const int r = e / c, i = e % c;
+        Ws[e] = (m0 + r < C) ? wo[(int64_t)(m0 + r) * C + h * c + i] : 0.f;
+    }
+    __syncthreads();
+    for (int e = tid; e < 16 * c; e += 256) {
+        const int r = e / c, j = e % c;
+        if (m0 + r >= C) continue;
+        float s = 0.f;
+        for (int i = 0; i < c; ++i) s = fmaf(Ws[r * c + i], As[i * c + j], s);
+        mfold[((int64_t)b * C + m0 + r) * C + h * c + j] = s;
+    }
+}
+
+
+// ---- backward ---------------------------------------------------------------------
+// One wave per row i of one (b,h); grid = (ceil(c/4), B*heads), block 256.
+//   dA_ij   = sum_m Wo[m][hc+i] * P[b][m][hc+j]
+//   dS_ij   = A_ij * (dA_ij - sum_j dA_ij A_ij)
+//   dtemp  += sum_ij dS_ij * Ghat_ij ;  dGhat = dS * temperature
+//   Eq_ij   = dGhat_ij / (nq_i nk_j)              (dq_i = sum_j Eq_ij k_j + Dq_i q_i)
+//   Dq_i    = -(sum_j dGhat_ij Ghat_ij) / nq_i^2  (0 where the norm was clamped)
+//   dGG_ij  = dGhat_ij * Ghat_ij                  (column sums give Dk)
+__global__ void __launch_bounds__(256)
+attn_bwd_rows_kernel(const float* __restrict__ P, const float* __restrict__ wo, const float* __restrict__ attn,
+                     const float* __restrict__ ghat, const float* __restrict__ nq, const float* __restrict__ nk,
+                     const float* __restrict__ temperature,
+                     float* __restrict__ Eq, float* __restrict__ Dq, float* __restrict__ dGG, float* __restrict__ dtemp_row,
+                     int C, int heads, int c) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // 4 rows x c
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int bh = blockIdx.y, b = bh / heads, h = bh % heads;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= c) return;
+    float* row = smem + wave * c;
+    const float* Pb = P + (int64_t)b * C * C + h * c;
+    const float* wcol = wo + h * c + i;
+    const int64_t rbase = ((int64_t)bh * c + i) * c;
+    float rs = 0.f;
+    for (int j = lane; j < c; j += 64) {
+        float s = 0.f;
+        for (int m = 0; m < C; ++m) s = fmaf(wcol[(int64_t)m * C], Pb[(int64_t)m * C + j], s);
+        row[j] = s;
+        rs = fmaf(s, attn[rbase + j], rs);
+    }
+    rs = wave_sum(rs);
+    const float temp = temperature[h];
+    const float nqi = nq[(int64_t)bh * c + i];
+    float dt = 0.f;
+    for (int j = lane; j < c; j += 64) {
+        const float a = attn[rbase + j], gh = ghat[rbase + j];
+        const float dS = a * (row[j] - rs);
+        dt = fmaf(dS, gh, dt);
+        const float dG = dS * temp;
+        Eq[rbase + j] = dG / (nqi * nk[(int64_t)bh * c + j]);
+        dGG[rbase + j] = dG * gh;
+    }
+    dt = wave_sum(dt);
+    if (lane == 0) {
+        dtemp_row[(int64_t)bh * c + i] = dt;
+        Dq[(int64_t)bh * c + i] = (nqi > NORM_EPS) ? -(dt * temp) / (nqi * nqi) : 0.f;
+    }
+}
+
+// grid = B*heads, block 256: Dk_j = -(sum_i dGG_ij)/nk_j^2, dtemp_b[bh] = sum_i dtemp_row[i]
+__global__ void __launch_bounds__(256)
+attn_bwd_cols_kernel(const float* __restrict__ dGG, const float* __restrict__ nk, const float* __restrict__ dtemp_row,
+                     float* __restrict__ Dk, float* __restrict__ dtemp_b, int c) {
+    __shared__ float red[4];
+    const int bh = blockIdx.x, tid = threadIdx.x;
+    for (int j = tid; j < c; j += 256) {
+        float s = 0.f;
+        for (int i = 0; i < c; ++i) s += dGG[((int64_t)bh * c + i) * c + j];
+        const float n = nk[(int64_t)bh * c + j];
+        Dk[(int64_t)bh * c + j] = (n > NORM_EPS) ? -s / (n * n) : 0.f;
+    }
+    float t = 0.f;
+    for (int i = tid; i < c; i += 256) t += dtemp_row[(int64_t)bh * c + i];
+    t = wave_sum(t);
+    if ((tid & 63) == 0) red[tid >> 6] = t;
+    __syncthreads();
+    if (tid == 0) dtemp_b[bh] = red[0] + red[1] + red[2] + red[3];
+}
+
+// dWo_b[b][m][hc+i] = sum_j P[b][m][hc+j] * A[b,h][i][j];  grid = (ceil(C/16), heads, B)
+__global__ void __launch_bounds__(256)
+attn_bwd_wo_kernel(const float* __restrict__ P, const float* __restrict__ attn, float* __restrict__ dwo_b,
+                   int C, int heads, int c) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // A: c*(c+1), P slab: 16*c
+    float* As = smem;
+    float* Ps = smem + c * (c + 1);
+    const int tid = threadIdx.x;
+    const int m0 = blockIdx.x * 16, h = blockIdx.y, b = blockIdx.z;
+    const float* Abh = attn + ((int64_t)b * heads + h) * c * c;
+    for (int e = tid; e < c * c; e += 256) As[(e / c) * (c + 1) + (e % c)] = Abh[e];
+    for (int e = tid; e < 16 * c; e += 256) {
+        const int r = e / c, j = e % c;
+        Ps[e] = (m0 + r < C) ? P[((int64_t)b * C + m0 + r) * C + h * c + j] : 0.f;
+    }
+    __syncthreads();
+    for (int e = tid; e < 16 * c; e += 256) {
+        const int r = e / c, i = e % c;
+        if (m0 + r >= C) continue;
+        float s = 0.f;
+        for (int j = 0; j < c; ++j) s = fmaf(Ps[r * c + j], As[i * (c + 1) + j], s);
+        dwo_b[((int64_t)b * C + m0 + r) * C + h * c + i] = s;
+    }
+}
+
+int attn_bwd_small_launch(const float* P, const float* wo, const float* attn, const float* ghat, const float* nq,
+                          const float* nk, const float* temperature, float* Eq, float* Dq, float* Dk, float* dGG,
+                          float* dtemp_row, float* dtemp_b, float* dwo_b, int B, int C, int heads, int c,
+                          hipStream_t stream) {
+    {
+        const size_t lds = (size_t)4 * c * sizeof(float);
+        RST_REQUIRE(lds <= 64 * 1024, "attention: channels per head %d too large", c);
+        dim3 grid((unsigned)cdiv(c, 4), (unsigned)(B * heads));
+        hipLaunchKernelGGL(attn_bwd_rows_kernel, grid, dim3(256), lds, stream, P, wo, attn, ghat, nq, nk, temperature,
+                           Eq, Dq, dGG, dtemp_row, C, heads, c);
+        RST_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(attn_bwd_cols_kernel, dim3((unsigned)(B * heads)), dim3(256), 0, stream, dGG, nk, dtemp_row, Dk,
+                       dtemp_b, c);
+    RST_LAUNCH_CHECK();
+    {
+        const size_t lds = (size_t)(c * (c + 1) + 16 * c) * sizeof(float);
+        RST_REQUIRE(lds <= 160 * 1024, "attention: channels per head %d too large", c);
+        if (lds > 64 * 1024)
+            RST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_wo_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        dim3 grid((unsigned)cdiv(C, 16), (unsigned)heads, (unsigned)B);
+        hipLaunchKernelGGL(attn_bwd_wo_kernel, grid, dim3(256), lds, stream, P, attn, dwo_b, C, heads, c);
+        RST_LAUNCH_CHECK();
+    }
+    return RST_OK;
+}
+
+int attn_softmax_launch(const float* gram_partial, const float* sqq_partial, const float* sqk_partial,
+                        const float* temperature, float* attn, float* ghat, float* nq, float* nk,
+                        int B, int heads, int c, int splits, hipStream_t stream) {
+    const size_t lds = (size_t)(c + 4 * c) * sizeof(float);
+    RST_REQUIRE(lds <= 64 * 1024, "attention: channels per head %d too large", c);
+    dim3 grid((unsigned)cdiv(c, 4), (unsigned)(B * heads));
+    hipLaunchKernelGGL(attn_softmax_kernel, grid, dim3(256), lds, stream, gram_partial, sqq_partial, sqk_partial,
+                       temperature, attn, ghat, nq, nk, heads, c, splits);
+    RST_LAUNCH_CHECK();
+    return RST_OK;
+}
+
+int attn_fold_launch(const float* wo, const float* attn, float* mfold, int B, int C, int heads, int c, hipStream_t stream) {
+    const size_t lds = (size_t)(c * c + 16 * c) * sizeof(float);
+    RST_REQUIRE(lds <= 160 * 1024, "attention: channels per head %d too large for the fold kernel", c);
+    if (lds > 64 * 1024)
+        RST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fold_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((unsigned)cdiv(C, 16), (unsigned)heads, (unsigned)B);
+    hipLaunchKernelGGL(attn_fold_kernel, grid, dim3(256), lds, stream, wo, attn, mfold, C, heads, c);
+    RST_LAUNCH_CHECK();
+    return RST_OK;
+}
+
+}  // namespace rst

@@ -1,0 +1,79 @@
+// Shared host/device helpers for the Restormer block kernels (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "../../include/restormer_hip.h"
+
+namespace rst {
+
+// ---- error reporting --------------------------------------------------------
+// Every C entry point returns an rst_status; the message of the last failure on
+// the calling thread is kept for rst_last_error().
+std::string& last_error_slot();
+
+inline int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    last_error_slot() = buf;
+    return code;
+}
+
+#define RST_REQUIRE(cond, ...)                                            \
+    do {                                                                  \
+        if (!(cond)) return ::rst::fail(RST_ERR_INVALID, __VA_ARGS__);    \
+    } while (0)
+
+#define RST_HIP(call)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return ::rst::fail(RST_ERR_HIP, "%s failed: %s (%s:%d)", #call,               \
+                               hipGetErrorString(e_), __FILE__, __LINE__);                \
+    } while (0)
+
+#define RST_LAUNCH_CHECK()                                                                \
+    do {                                                                                  \
+        hipError_t e_ = hipGetLastError();                                                \
+        if (e_ != hipSuccess)                                                             \
+            return ::rst::fail(RST_ERR_HIP, "kernel launch failed: %s (%s:%d)",           \
+                               hipGetErrorString(e_), __FILE__, __LINE__);                \
+    } while (0)
+
+#define RST_TRY(expr)                 \
+    do {                              \
+        int s_ = (expr);              \
+        if (s_ != RST_OK) return s_;  \
+    } while (0)
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline int64_t round_up(int64_t a, int64_t b) { return cdiv(a, b) * b; }
+
+// ---- device helpers ---------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+// d/dx [ 0.5 x (1 + erf(x/sqrt2)) ] = 0.5 (1 + erf(x/sqrt2)) + x * exp(-x^2/2) / sqrt(2 pi)
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) +
+           x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+
+}  // namespace rst

@@ -1,0 +1,287 @@
+// G[g] = sum over pixels (and optionally over samples) of A[:, n] * Bm[:, n]^T
+//
+// The "reduce over all H*W pixels" products of the block:
+//   * MDTA Gram matrix q k^T per (sample, head) together with the squared L2
+//     norms of every q and k row (model/Restromer.py:137-140), K = H*W
+//   * weight gradients of the 1x1 convolutions, dW = sum_b dY[b] X[b]^T
+//   * dY v^T in the attention backward
+// M1, M2 are small (<= 1152) and the contraction runs over up to millions of
+// pixels, so the pixel axis is split over many workgroups (split-K): each
+// block reduces its pixel range on the matrix cores (exact fp32
+// v_mfma_f32_16x16x4_f32) and writes one partial slab; a second pass adds the
+// slabs in a fixed order, so results are bitwise reproducible.
+//
+// A and Bm are read straight from their NCHW planes: 16 lanes x 16 B cover 64
+// consecutive pixels of one channel row.  In LDS a row keeps its pixels
+// contiguous; MFMA lane (i, kk) takes pixels 4*kk..4*kk+3 of row i with one
+// ds_read_b128 and feeds them to four consecutive k-steps (the k order inside
+// a 16-pixel group is permuted identically for both operands, which leaves the
+// sum unchanged).
+#include "kernels.hpp"
+
+namespace rst {
+
+
+constexpr int NT_KP = 64;          // pixels staged per iteration
+constexpr int NT_LD = NT_KP + 4;   // LDS row stride (floats): 17 x 16 B
+
+// T1,T2: 16-row tiles per wave along M1/M2.  WR x WC x WK = 4 waves: WR*WC
+// waves tile the output, WK waves split the staged pixels.
+template <int T1, int T2, bool VEC>
+__global__ void __launch_bounds__(256)
+gemm_nt_kernel(GemmNT g, int WR, int WC, int rblocks, int cblocks) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int WK = 4 / (WR * WC);
+    const int R1 = 16 * T1 * WR, R2 = 16 * T2 * WC;     // block tile
+    float* As = smem;
+    float* Bs = smem + R1 * NT_LD;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int bid = blockIdx.x;
+    const int cb = bid % cblocks; bid /= cblocks;
+    const int rb = bid % rblocks; bid /= rblocks;
+    const int sp = bid % g.splits; bid /= g.splits;
+    const int batch = bid;
+    const int b1 = batch / g.nb2, b2 = batch % g.nb2;
+
+    const float* Ab = g.A + (int64_t)b1 * g.a_s1 + (int64_t)b2 * g.a_s2 + (int64_t)(rb * R1) * g.lda;
+    const float* Bb = g.Bm + (int64_t)b1 * g.b_s1 + (int64_t)b2 * g.b_s2 + (int64_t)(cb * R2) * g.ldb;
+    const int rowsA = min(R1, g.M1 - rb * R1);     // valid rows in this tile
+    const int rowsB = min(R2, g.M2 - cb * R2);
+    const int64_t p_begin = (int64_t)sp * g.chunk;
+    const int64_t p_end = min(g.N, p_begin + g.chunk);
+
+    // staging: thread -> 4 pixels at (tid&15)*4 of rows (tid>>4) + 16*i
+    const int sc = (tid & 15) * 4, sr = tid >> 4;
+    constexpr int MAXR = 8;                       // up to 128 rows per operand
+    f32x4 ra[MAXR], rbv[MAXR];
+    float sqa[MAXR], sqb[MAXR];
+#pragma unroll
+    for (int i = 0; i < MAXR; ++i) { sqa[i] = 0.f; sqb[i] = 0.f; }
+    const int itA = R1 / 16, itB = R2 / 16;
+
+    auto load_rows = [&](f32x4* dst, const float* base, int64_t ld, int rows, int iters, int64_t p) {
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            if (i < iters) {
+                const int r = sr + 16 * i;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                const int64_t n = p + sc;
+                if (r < rows) {
+                    const float* src = base + (int64_t)r * ld + n;
+                    if constexpr (VEC) {
+                        if (n < p_end) v = *reinterpret_cast<const f32x4*>(src);   // p_end % 4 == 0
+                    } else {
+                        if (n + 0 < p_end) v.x = src[0];
+                        if (n + 1 < p_end) v.y = src[1];
+                        if (n + 2 < p_end) v.z = src[2];
+                        if (n + 3 < p_end) v.w = src[3];
+                    }
+                }
+                dst[i] = v;
+            }
+        }
+    };
+
+    f32x4 acc[T1][T2];
+#pragma unroll
+    for (int i = 0; i < T1; ++i)
+#pragma unroll
+        for (int j = 0; j < T2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int wk = wave % WK;
+    const int wt = wave / WK;
+    const int wr = wt / WC, wc = wt % WC;
+    const int li = lane & 15, kk = lane >> 4;
+    const int px_per_wave = NT_KP / WK;            // 64, 32 or 16
+
+    if (p_begin < p_end) {
+        load_rows(ra, Ab, g.lda, rowsA, itA, p_begin);
+        load_rows(rbv, Bb, g.ldb, rowsB, itB, p_begin);
+    }
+    for (int64_t p = p_begin; p < p_end; p += NT_KP) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            if (i < itA) {
+                *reinterpret_cast<f32x4*>(&As[(sr + 16 * i) * NT_LD + sc]) = ra[i];
+                sqa[i] += ra[i].x * ra[i].x + ra[i].y * ra[i].y + ra[i].z * ra[i].z + ra[i].w * ra[i].w;
+            }
+            if (i < itB) {
+                *reinterpret_cast<f32x4*>(&Bs[(sr + 16 * i) * NT_LD + sc]) = rbv[i];
+                sqb[i] += rbv[i].x * rbv[i].x + rbv[i].y * rbv[i].y + rbv[i].z * rbv[i].z + rbv[i].w * rbv[i].w;
+            }
+        }
+        __syncthreads();
+        if (p + NT_KP < p_end) {
+            load_rows(ra, Ab, g.lda, rowsA, itA, p + NT_KP);
+            load_rows(rbv, Bb, g.ldb, rowsB, itB, p + NT_KP);
+        }
+        for (int q = 0; q < px_per_wave; q += 16) {
+            const int px = wk * px_per_wave + q + 4 * kk;
+            f32x4 av[T1], bv[T2];
+#pragma unroll
+            for (int i = 0; i < T1; ++i)
+                av[i] = *reinterpret_cast<const f32x4*>(&As[(wr * 16 * T1 + 16 * i + li) * NT_LD + px]);
+#pragma unroll
+            for (int j = 0; j < T2; ++j)
+                bv[j] = *reinterpret_cast<const f32x4*>(&Bs[(wc * 16 * T2 + 16 * j + li) * NT_LD + px]);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < T1; ++i)
+#pragma unroll
+                    for (int j = 0; j < T2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][s], bv[j][s], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- combine the WK pixel-split waves through LDS, then write the slab ----
+    __syncthreads();
+    float* red = smem;        // reuse: [WK][WR*WC][T1*T2][64 lanes][4]
+    if (WK > 1) {
+#pragma unroll
+        for (int i = 0; i < T1; ++i)
+#pragma unroll
+            for (int j = 0; j < T2; ++j)
+                *reinterpret_cast<f32x4*>(&red[(((wk * (WR * WC) + wt) * (T1 * T2) + i * T2 + j) * 64 + lane) * 4]) = acc[i][j];
+        __syncthreads();
+    }
+    float* slab = g.partial + ((int64_t)batch * g.splits + sp) * (int64_t)g.M1 * g.M2;
+    if (wk == 0) {
+#pragma unroll
+        for (int i = 0; i < T1; ++i)
+#pragma unroll
+            for (int j = 0; j < T2; ++j) {
+                f32x4 v = acc[i][j];
+                for (int w = 1; w < WK; ++w) {
+                    const f32x4 o = *reinterpret_cast<const f32x4*>(&red[(((w * (WR * WC) + wt) * (T1 * T2) + i * T2 + j) * 64 + lane) * 4]);
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
+                const int col = cb * R2 + wc * 16 * T2 + 16 * j + li;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rb * R1 + wr * 16 * T1 + 16 * i + 4 * kk + r;
+                    if (row < g.M1 && col < g.M2) slab[(int64_t)row * g.M2 + col] = v[r];
+                }
+            }
+    }
+    // ---- squared norms: the 16 lanes (tid&15) that staged a row hold its partial sums ----
+    if (g.sqA_partial != nullptr && cb == 0) {
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            if (i < itA) {
+                float s = sqa[i];
+                s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
+                s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+                const int row = rb * R1 + sr + 16 * i;
+                if ((tid & 15) == 0 && row < g.M1)
+                    g.sqA_partial[((int64_t)batch * g.splits + sp) * g.M1 + row] = s;
+            }
+        }
+    }
+    if (g.sqB_partial != nullptr && rb == 0) {
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            if (i < itB) {
+                float s = sqb[i];
+                s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
+                s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+                const int row = cb * R2 + sr + 16 * i;
+                if ((tid & 15) == 0 && row < g.M2)
+                    g.sqB_partial[((int64_t)batch * g.splits + sp) * g.M2 + row] = s;
+            }
+        }
+    }
+}
+
+// out[g][e] (+)= sum_{i < slabs_per_group} partial[(g*slabs_per_group + i)][e], fixed order
+__global__ void reduce_slabs_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                    int64_t elems, int slabs_per_group, int accumulate) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t grp = blockIdx.y;
+    if (e >= elems) return;
+    const float* p = partial + grp * slabs_per_group * elems + e;
+    float s = 0.f;
+    for (int i = 0; i < slabs_per_group; ++i) s += p[(int64_t)i * elems];
+    float* dst = out + grp * elems + e;
+    *dst = accumulate ? (*dst + s) : s;
+}
+
+// Tile plan along one output dimension: 16*T rows per wave, W waves.
+static NtDim nt_pick_dim(int M, int maxW) {
+    NtDim best{1, 1, (int)cdiv(M, 16)};
+    int64_t best_pad = INT64_MAX;
+    for (int W = 1; W <= maxW; W *= 2)
+        for (int T = 1; T <= 4; ++T) {
+            const int rows = 16 * T * W;
+            if (rows > 128) continue;
+            const int blocks = (int)cdiv(M, rows);
+            const int64_t pad = (int64_t)blocks * rows;
+            // least padding; ties -> fewer blocks (bigger tiles), then fewer waves (keeps WK large)
+            if (pad < best_pad || (pad == best_pad && (blocks < best.blocks || (blocks == best.blocks && W < best.W)))) {
+                best = NtDim{T, W, blocks}; best_pad = pad;
+            }
+        }
+    return best;
+}
+
+
+NtPlan gemm_nt_plan(int M1, int M2, int64_t N, int nbatch) {
+    NtPlan p;
+    p.d1 = nt_pick_dim(M1, 2);
+    p.d2 = nt_pick_dim(M2, 2);
+    const int64_t tiles = (int64_t)p.d1.blocks * p.d2.blocks * nbatch;
+    // aim for ~1024 blocks on the chip, at least 512 pixels per block
+    int64_t want = cdiv(1024, tiles);
+    int64_t max_splits = cdiv(N, 512);
+    if (want > max_splits) want = max_splits;
+    if (want < 1) want = 1;
+    p.chunk = round_up(cdiv(N, want), 64);
+    p.splits = (int)cdiv(N, p.chunk);
+    return p;
+}
+
+size_t gemm_nt_partial_floats(const NtPlan& p, int M1, int M2, int nbatch) {
+    return (size_t)nbatch * p.splits * (size_t)M1 * M2;
+}
+
+int gemm_nt_launch(GemmNT g, const NtPlan& p, hipStream_t stream) {
+    RST_REQUIRE(g.M1 > 0 && g.M2 > 0 && g.N > 0 && g.nb1 > 0 && g.nb2 > 0, "gemm_nt: empty problem");
+    RST_REQUIRE(g.A && g.Bm && g.partial, "gemm_nt: null operand");
+    g.splits = p.splits; g.chunk = p.chunk;
+    const int WR = p.d1.W, WC = p.d2.W;
+    const int64_t grid = (int64_t)g.nb1 * g.nb2 * p.splits * p.d1.blocks * p.d2.blocks;
+    RST_REQUIRE(grid < (1ll << 31), "gemm_nt: grid too large");
+    const bool vec = (g.N % 4 == 0) && (g.lda % 4 == 0) && (g.ldb % 4 == 0) && (g.a_s1 % 4 == 0) && (g.a_s2 % 4 == 0) &&
+                     (g.b_s1 % 4 == 0) && (g.b_s2 % 4 == 0) && aligned16(g.A) && aligned16(g.Bm);
+    const int R1 = 16 * p.d1.T * WR, R2 = 16 * p.d2.T * WC;
+    const int WK = 4 / (WR * WC);
+    size_t lds = (size_t)(R1 + R2) * NT_LD * sizeof(float);
+    const size_t red = (size_t)WK * WR * WC * p.d1.T * p.d2.T * 64 * 4 * sizeof(float);
+    if (WK > 1 && red > lds) lds = red;
+    dim3 gd((unsigned)grid), blk(256);
+#define NT_CASE(a, b)                                                                                         \
+    if (p.d1.T == a && p.d2.T == b) {                                                                         \
+        if (vec) hipLaunchKernelGGL((gemm_nt_kernel<a, b, true>), gd, blk, lds, stream, g, WR, WC, p.d1.blocks, p.d2.blocks);  \
+        else     hipLaunchKernelGGL((gemm_nt_kernel<a, b, false>), gd, blk, lds, stream, g, WR, WC, p.d1.blocks, p.d2.blocks); \
+    } else
+    NT_CASE(1, 1) NT_CASE(1, 2) NT_CASE(1, 3) NT_CASE(1, 4)
+    NT_CASE(2, 1) NT_CASE(2, 2) NT_CASE(2, 3) NT_CASE(2, 4)
+    NT_CASE(3, 1) NT_CASE(3, 2) NT_CASE(3, 3) NT_CASE(3, 4)
+    NT_CASE(4, 1) NT_CASE(4, 2) NT_CASE(4, 3) NT_CASE(4, 4)
+    { return fail(RST_ERR_INVALID, "gemm_nt: bad tile"); }
+#undef NT_CASE
+    RST_LAUNCH_CHECK();
+    return RST_OK;
+}
+
+int reduce_slabs_launch(const float* partial, float* out, int64_t elems, int groups, int slabs_per_group,
+                        int accumulate, hipStream_t stream) {
+    dim3 gd((unsigned)cdiv(elems, 256), (unsigned)groups), blk(256);
+    hipLaunchKernelGGL(reduce_slabs_kernel, gd, blk, 0, stream, partial, out, elems, slabs_per_group, accumulate);
+    RST_LAUNCH_CHECK();
+    return RST_OK;
+}
+
+}  // namespace rst

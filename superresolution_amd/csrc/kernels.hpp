@@ -1,0 +1,92 @@
+// Internal launch interface between the kernel files and the C ABI (api.hip).
+#pragma once
+#include "common.hpp"
+
+namespace rst {
+
+// ---- layernorm.hip ----
+int layernorm_fwd_launch(const float* x, const float* weight, const float* bias, float* y,
+                         int B, int C, int64_t N, hipStream_t stream);
+size_t layernorm_bwd_ws_bytes(int B, int C, int64_t N);
+int layernorm_bwd_launch(const float* x, const float* weight, int with_bias, const float* dy,
+                         const float* addend, float* dx, float* dweight, float* dbias,
+                         int B, int C, int64_t N, void* ws, size_t ws_bytes, hipStream_t stream);
+// dx = addend + LN-backward(dy); addend may be null or alias dx.
+
+// ---- gemm_nn.hip ----
+struct GemmNN {
+    const float* A; int64_t a_s1, a_s2; int lda; int transA;
+    const float* X; int64_t x_s1, x_s2; int64_t ldx;
+    float* Y;       int64_t y_s1, y_s2; int64_t ldy;
+    const float* R; int64_t r_s1, r_s2; int64_t ldr;
+    const float* rscale; int64_t rs_s1, rs_s2;
+    const float* bias;
+    int M, K; int64_t N; int nb1, nb2;
+    int accumulate;
+};
+int gemm_nn_launch(const GemmNN& g, hipStream_t stream);
+
+// ---- gemm_nt.hip ----
+struct GemmNT {
+    const float* A; int64_t a_s1, a_s2; int64_t lda;
+    const float* Bm; int64_t b_s1, b_s2; int64_t ldb;
+    int M1, M2; int64_t N;
+    int nb1, nb2;
+    int splits; int64_t chunk;
+    float* partial;
+    float* sqA_partial;
+    float* sqB_partial;
+};
+struct NtDim { int T, W, blocks; };
+struct NtPlan { NtDim d1, d2; int splits; int64_t chunk; };
+NtPlan gemm_nt_plan(int M1, int M2, int64_t N, int nbatch);
+size_t gemm_nt_partial_floats(const NtPlan& p, int M1, int M2, int nbatch);
+int gemm_nt_launch(GemmNT g, const NtPlan& p, hipStream_t stream);
+int reduce_slabs_launch(const float* partial, float* out, int64_t elems, int groups, int slabs_per_group,
+                        int accumulate, hipStream_t stream);
+
+// ---- dwconv.hip ----
+struct DwArgs {
+    const float* x; int64_t x_bstride;
+    const float* w;
+    const float* bias;
+    float* y; int64_t y_bstride;
+    int B, C, H, W;
+    int flip;
+};
+struct GateArgs {
+    const float* u; int64_t u_bstride;
+    const float* w; const float* bias;
+    float* gout; int64_t g_bstride;
+    float* d; int64_t d_bstride;
+    int B, hidden, H, W;
+};
+int dwconv_fwd_launch(const DwArgs& a, hipStream_t stream);
+int dwconv_gate_fwd_launch(const GateArgs& a, hipStream_t stream);
+int gate_bwd_launch(const float* dg, const float* d, float* dd, int B, int hidden, int64_t hw, hipStream_t stream);
+size_t dwconv_bwd_weight_ws_bytes(int B, int C, int H, int W);
+int dwconv_bwd_weight_launch(const float* x, int64_t x_bstride, const float* dy, int64_t dy_bstride,
+                             float* dweight, float* dbias, int B, int C, int H, int W,
+                             void* ws, size_t ws_bytes, hipStream_t stream);
+
+// ---- shuffle.hip ----
+int pixel_shuffle2_launch(bool shuffle, const float* src, float* dst, int B, int C, int H, int W, hipStream_t stream);
+
+// ---- attn_small.hip ----
+int attn_softmax_launch(const float* gram_partial, const float* sqq_partial, const float* sqk_partial,
+                        const float* temperature, float* attn, float* ghat, float* nq, float* nk,
+                        int B, int heads, int c, int splits, hipStream_t stream);
+int attn_fold_launch(const float* wo, const float* attn, float* mfold, int B, int C, int heads, int c, hipStream_t stream);
+
+int attn_bwd_small_launch(const float* P, const float* wo, const float* attn, const float* ghat, const float* nq,
+                          const float* nk, const float* temperature, float* Eq, float* Dq, float* Dk, float* dGG,
+                          float* dtemp_row, float* dtemp_b, float* dwo_b, int B, int C, int heads, int c,
+                          hipStream_t stream);
+
+// ---- reduce.hip ----
+// out[row] = sum over batch and pixels of x[b][row][n]
+size_t rowsum_ws_bytes(int B, int rows, int64_t N);
+int rowsum_launch(const float* x, int64_t x_bstride, float* out, int B, int rows, int64_t N,
+                  void* ws, size_t ws_bytes, hipStream_t stream);
+
+}  // namespace rst

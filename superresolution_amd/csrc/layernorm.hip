@@ -1,0 +1,337 @@
+// Channel LayerNorm over NCHW, forward and backward (reference:
+// model/Restromer.py:20-74).  HBM-bound: 2*C*4 bytes per pixel each way.
+//
+// Layout of a block: a tile of 64*VEC consecutive pixels of one sample; lane l
+// of every wave owns pixels [l*VEC, l*VEC+VEC) of the tile, and the block's
+// waves split the channels round-robin (wave w owns channels w, w+WAVES, ...).
+// Adjacent lanes read adjacent pixels, so every load/store instruction of a
+// wave is one fully coalesced 64*VEC*4-byte segment of one channel plane.  The
+// whole channel column of a pixel stays in registers between the statistics
+// and the normalisation, so x is read from HBM exactly once.
+#include "kernels.hpp"
+
+namespace rst {
+
+template <int VEC> struct VecT;
+template <> struct VecT<1> { typedef float type; };
+template <> struct VecT<4> { typedef f32x4 type; };
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(float (&dst)[VEC], const float* p) {
+    if constexpr (VEC == 4) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(p);
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    } else {
+        dst[0] = *p;
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void store_vec(float* p, const float (&src)[VEC]) {
+    if constexpr (VEC == 4) {
+        f32x4 v = {src[0], src[1], src[2], src[3]};
+        *reinterpret_cast<f32x4*>(p) = v;
+    } else {
+        *p = src[0];
+    }
+}
+
+// Sum `v[0..VEC)` over the waves of the block (each wave holds a partial for
+// the same pixels).  red: [WAVES][64*VEC] floats of LDS.
+template <int VEC>
+__device__ __forceinline__ void block_channel_sum(float (&v)[VEC], float* red, int waves, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) red[wave * 64 * VEC + lane * VEC + i] = v[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+        float s = 0.f;
+        for (int w = 0; w < waves; ++w) s += red[w * 64 * VEC + lane * VEC + i];
+        v[i] = s;
+    }
+}
+
+template <int VEC, int CPT>
+__global__ void __launch_bounds__(512)
+ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ weight, const float* __restrict__ bias,
+              float* __restrict__ y, int C, int64_t N, int64_t tiles_per_sample) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int waves = blockDim.x >> 6;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t b = blockIdx.x / tiles_per_sample;
+    const int64_t p0 = (blockIdx.x % tiles_per_sample) * (64 * VEC) + lane * VEC;
+    const bool pix_ok = p0 < N;     // N % VEC == 0 is guaranteed by the launcher
+    const float* xb = x + b * (int64_t)C * N;
+    float* yb = y + b * (int64_t)C * N;
+
+    float v[CPT][VEC];
+    float s[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) s[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int c = wave + j * waves;
+        if (c < C && pix_ok) {
+            load_vec<VEC>(v[j], xb + (int64_t)c * N + p0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[j][i] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s[i] += v[j][i];
+    }
+    float* red0 = smem;
+    float* red1 = smem + waves * 64 * VEC;
+    block_channel_sum<VEC>(s, red0, waves, wave, lane);
+    float mu[VEC], q[VEC];
+    const float invC = 1.0f / (float)C;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) { mu[i] = s[i] * invC; q[i] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int c = wave + j * waves;
+        if (c < C) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) { float d = v[j][i] - mu[i]; q[i] += d * d; }
+        }
+    }
+    block_channel_sum<VEC>(q, red1, waves, wave, lane);
+    float rstd[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) rstd[i] = 1.0f / sqrtf(q[i] * invC + 1e-5f);
+
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int c = wave + j * waves;
+        if (c < C && pix_ok) {
+            const float w = weight[c];
+            float o[VEC];
+            if (bias != nullptr) {
+                const float bb = bias[c];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) o[i] = (v[j][i] - mu[i]) * rstd[i] * w + bb;
+            } else {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) o[i] = v[j][i] * rstd[i] * w;
+            }
+            store_vec<VEC>(yb + (int64_t)c * N + p0, o);
+        }
+    }
+}
+
+// Backward.  With g = dy*w, xh = (x-mu)*rstd:
+//   WithBias: dx = rstd * (g - mean_c(g) - xh * mean_c(g*xh));  dw = sum dy*xh;  db = sum dy
+//   BiasFree: y = x*rstd*w  =>  dx = rstd*g - rstd^3 * (x-mu) * mean_c(g*x);  dw = sum dy*x*rstd
+// Blocks stride over tiles and keep per-channel partial sums of dw/db in
+// registers; one partial row per block goes to `partial` ([grid][2][C]) and a
+// second kernel adds the rows in a fixed order (deterministic).
+template <int VEC, int CPT>
+__global__ void __launch_bounds__(512)
+ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ weight, int with_bias,
+              const float* __restrict__ dy, const float* addend, float* dx,
+              float* __restrict__ partial, int C, int64_t N, int64_t tiles_per_sample, int64_t total_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int waves = blockDim.x >> 6;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* red0 = smem;
+    float* red1 = smem + waves * 64 * VEC;
+    const float invC = 1.0f / (float)C;
+
+    float pw[CPT], pb[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) { pw[j] = 0.f; pb[j] = 0.f; }
+
+    for (int64_t tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        const int64_t b = tile / tiles_per_sample;
+        const int64_t p0 = (tile % tiles_per_sample) * (64 * VEC) + lane * VEC;
+        const bool pix_ok = p0 < N;
+        const int64_t base = b * (int64_t)C * N + p0;
+
+        float v[CPT][VEC], g[CPT][VEC];
+        float s[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) s[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int c = wave + j * waves;
+            if (c < C && pix_ok) {
+                load_vec<VEC>(v[j], x + base + (int64_t)c * N);
+                load_vec<VEC>(g[j], dy + base + (int64_t)c * N);
+            } else {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) { v[j][i] = 0.f; g[j][i] = 0.f; }
+            }
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) s[i] += v[j][i];
+        }
+        block_channel_sum<VEC>(s, red0, waves, wave, lane);
+        float mu[VEC], q[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { mu[i] = s[i] * invC; q[i] = 0.f; }
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int c = wave + j * waves;
+            if (c < C) {
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) { float d = v[j][i] - mu[i]; q[i] += d * d; }
+            }
+        }
+        block_channel_sum<VEC>(q, red1, waves, wave, lane);
+        float rstd[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) rstd[i] = 1.0f / sqrtf(q[i] * invC + 1e-5f);
+
+        // parameter-gradient partials use dy itself; afterwards g <- dy * w
+        float s1[VEC], s2[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int c = wave + j * waves;
+            if (c < C) {
+                const float w = weight[c];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const float dyv = g[j][i];
+                    const float xh = with_bias ? (v[j][i] - mu[i]) * rstd[i] : v[j][i] * rstd[i];
+                    pw[j] += dyv * xh;
+                    pb[j] += dyv;
+                    const float gw = dyv * w;
+                    g[j][i] = gw;
+                    s1[i] += gw;
+                    s2[i] += with_bias ? gw * xh : gw * v[j][i];
+                }
+            }
+        }
+        __syncthreads();   // red0/red1 are reused below
+        block_channel_sum<VEC>(s1, red0, waves, wave, lane);
+        block_channel_sum<VEC>(s2, red1, waves, wave, lane);
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const int c = wave + j * waves;
+            if (c < C && pix_ok) {
+                float o[VEC];
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    if (with_bias) {
+                        const float xh = (v[j][i] - mu[i]) * rstd[i];
+                        o[i] = rstd[i] * (g[j][i] - s1[i] * invC - xh * (s2[i] * invC));
+                    } else {
+                        const float r = rstd[i];
+                        o[i] = r * g[j][i] - r * r * r * (v[j][i] - mu[i]) * (s2[i] * invC);
+                    }
+                }
+                float* dst = dx + base + (int64_t)c * N;
+                if (addend != nullptr) {
+                    float old[VEC];
+                    load_vec<VEC>(old, addend + base + (int64_t)c * N);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) o[i] += old[i];
+                }
+                store_vec<VEC>(dst, o);
+            }
+        }
+        __syncthreads();
+    }
+    // one partial row per block
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int c = wave + j * waves;
+        const float a = wave_sum(pw[j]);
+        const float bsum = wave_sum(pb[j]);
+        if (lane == 0 && c < C) {
+            partial[((int64_t)blockIdx.x * 2 + 0) * C + c] = a;
+            partial[((int64_t)blockIdx.x * 2 + 1) * C + c] = bsum;
+        }
+    }
+}
+
+// out[r][c] = sum_i partial[i][r][c]  (i over rows), fixed order.
+__global__ void ln_reduce_partials_kernel(const float* __restrict__ partial, int rows, int C,
+                                          float* __restrict__ dweight, float* __restrict__ dbias) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f, b = 0.f;
+    for (int i = 0; i < rows; ++i) {
+        a += partial[((int64_t)i * 2 + 0) * C + c];
+        b += partial[((int64_t)i * 2 + 1) * C + c];
+    }
+    dweight[c] = a;
+    if (dbias != nullptr) dbias[c] = b;
+}
+
+// ---- launch plan --------------------------------------------------------------
+struct LnPlan {
+    int vec, cpt, waves;
+};
+static bool ln_plan(int C, int64_t N, bool ptr_aligned, bool backward, LnPlan* p) {
+    // At most 8 waves (512 threads -> 256 registers per lane); the channel
+    // column of a pixel (and of dy in the backward) stays in registers.
+    int waves = (int)cdiv(C, 12);
+    if (waves > 8) waves = 8;
+    const int cpt = (int)cdiv(C, waves);
+    if (cpt <= 12) p->cpt = 12;
+    else if (cpt <= 24) p->cpt = 24;
+    else if (cpt <= 48) p->cpt = 48;
+    else return false;
+    const int max_vec_cpt = backward ? 12 : 24;
+    p->vec = (N % 4 == 0 && ptr_aligned && p->cpt <= max_vec_cpt) ? 4 : 1;
+    p->waves = waves;
+    return true;
+}
+
+static const int LN_BWD_MAX_BLOCKS = 1024;
+
+int layernorm_fwd_launch(const float* x, const float* weight, const float* bias, float* y,
+                         int B, int C, int64_t N, hipStream_t stream) {
+    LnPlan p;
+    RST_REQUIRE(ln_plan(C, N, aligned16(x) && aligned16(y), false, &p), "layernorm: C=%d too large (max 384)", C);
+    const int64_t tps = cdiv(N, 64 * p.vec);
+    const int64_t grid = (int64_t)B * tps;
+    RST_REQUIRE(grid > 0 && grid < (1ll << 31), "layernorm: grid out of range");
+    const size_t lds = (size_t)2 * p.waves * 64 * p.vec * sizeof(float);
+    dim3 blk(p.waves * 64);
+#define LN_FWD(V, CP) hipLaunchKernelGGL((ln_fwd_kernel<V, CP>), dim3((unsigned)grid), blk, lds, stream, x, weight, bias, y, C, N, tps)
+    if (p.vec == 4 && p.cpt == 12) LN_FWD(4, 12);
+    else if (p.vec == 4 && p.cpt == 24) LN_FWD(4, 24);
+    else if (p.vec == 1 && p.cpt == 12) LN_FWD(1, 12);
+    else if (p.vec == 1 && p.cpt == 24) LN_FWD(1, 24);
+    else LN_FWD(1, 48);
+#undef LN_FWD
+    RST_LAUNCH_CHECK();
+    return RST_OK;
+}
+
+size_t layernorm_bwd_ws_bytes(int B, int C, int64_t N) {
+    (void)B; (void)N;
+    return (size_t)LN_BWD_MAX_BLOCKS * 2 * (size_t)C * sizeof(float);
+}
+
+int layernorm_bwd_launch(const float* x, const float* weight, int with_bias, const float* dy,
+                         const float* addend, float* dx, float* dweight, float* dbias,
+                         int B, int C, int64_t N, void* ws, size_t ws_bytes, hipStream_t stream) {
+    LnPlan p;
+    RST_REQUIRE(ln_plan(C, N, aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(addend), true, &p),
+                "layernorm: C=%d too large (max 384)", C);
+    if (ws == nullptr || ws_bytes < layernorm_bwd_ws_bytes(B, C, N))
+        return fail(RST_ERR_WORKSPACE, "layernorm_bwd: workspace too small (%zu < %zu)", ws_bytes,
+                    layernorm_bwd_ws_bytes(B, C, N));
+    const int64_t tps = cdiv(N, 64 * p.vec);
+    const int64_t total = (int64_t)B * tps;
+    const int grid = (int)(total < LN_BWD_MAX_BLOCKS ? total : LN_BWD_MAX_BLOCKS);
+    const size_t lds = (size_t)2 * p.waves * 64 * p.vec * sizeof(float);
+    dim3 blk(p.waves * 64);
+    float* partial = static_cast<float*>(ws);
+#define LN_BWD(V, CP) hipLaunchKernelGGL((ln_bwd_kernel<V, CP>), dim3(grid), blk, lds, stream, x, weight, with_bias, dy, addend, dx, partial, C, N, tps, total)
+    if (p.vec == 4 && p.cpt == 12) LN_BWD(4, 12);
+    else if (p.vec == 1 && p.cpt == 12) LN_BWD(1, 12);
+    else if (p.vec == 1 && p.cpt == 24) LN_BWD(1, 24);
+    else LN_BWD(1, 48);
+#undef LN_BWD
+    RST_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ln_reduce_partials_kernel, dim3((unsigned)cdiv(C, 128)), dim3(128), 0, stream,
+                       partial, grid, C, dweight, with_bias ? dbias : nullptr);
+    RST_LAUNCH_CHECK();
+    return RST_OK;
+}
+
+}  // namespace rst

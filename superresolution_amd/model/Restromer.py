@@ -1,0 +1,257 @@
+"""Drop-in module surface of the reference's ``model/Restromer.py`` on MI355X.
+
+Same class names, constructor signatures, parameter names/shapes/registration
+order and forward signatures as the reference (citations per class), so a
+reference ``state_dict`` loads with ``strict=True`` and optimiser state keeps
+its parameter order.  The parameters live in ordinary ``nn.Conv2d`` /
+``nn.Parameter`` containers (identical default initialisation), but no forward
+here runs a torch convolution for the TransformerBlock path: every block,
+LayerNorm, attention, feed-forward and pixel (un)shuffle goes through the
+hand-written HIP kernels in ``librestormer_hip.so``.  Inputs must be fp32
+tensors on a ROCm device; anything else raises ``RuntimeError``.
+"""
+from __future__ import annotations
+
+import numbers
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+
+def _flat(conv: nn.Conv2d):
+    return conv.weight, conv.bias
+
+
+# ----------------------------------------------------------------------------
+# (b c h w) <-> (b hw c) views, reference model/Restromer.py:20-25.  Kept for API
+# compatibility; the kernels normalise NCHW directly and never need them.
+# ----------------------------------------------------------------------------
+def to_3d(x):
+    b, c, h, w = x.shape
+    return x.reshape(b, c, h * w).transpose(1, 2)
+
+
+def to_4d(x, h, w):
+    b, hw, c = x.shape
+    return x.transpose(1, 2).reshape(b, c, h, w)
+
+
+class _ChannelNormBase(nn.Module):
+    """Holds ``weight`` (and ``bias``) of shape (C,).  ``forward`` follows the
+    reference bodies, which take the (b, hw, c) view (model/Restromer.py:40-42,
+    58-61); LayerNorm below calls the NCHW kernel directly instead."""
+    with_bias = False
+
+    def __init__(self, normalized_shape):
+        super().__init__()
+        if isinstance(normalized_shape, numbers.Integral):
+            normalized_shape = (normalized_shape,)
+        normalized_shape = torch.Size(normalized_shape)
+        if len(normalized_shape) != 1:
+            raise AssertionError("channel LayerNorm takes a single normalised dimension")
+        self.weight = nn.Parameter(torch.ones(normalized_shape))
+        if self.with_bias:
+            self.bias = nn.Parameter(torch.zeros(normalized_shape))
+        self.normalized_shape = normalized_shape
+
+    def forward(self, x):
+        # x: (b, hw, c)  ->  NCHW with W = 1, run the kernel, and back
+        b, n, c = x.shape
+        y = ops.layernorm(x.transpose(1, 2).reshape(b, c, n, 1), self.weight, self.bias if self.with_bias else None)
+        return y.reshape(b, c, n).transpose(1, 2)
+
+
+class BiasFree_LayerNorm(_ChannelNormBase):      # reference model/Restromer.py:28-42
+    with_bias = False
+
+
+class WithBias_LayerNorm(_ChannelNormBase):      # reference model/Restromer.py:45-61
+    with_bias = True
+
+
+class LayerNorm(nn.Module):
+    """reference model/Restromer.py:64-74"""
+
+    def __init__(self, dim, LayerNorm_type):
+        super().__init__()
+        self.body = BiasFree_LayerNorm(dim) if LayerNorm_type == "BiasFree" else WithBias_LayerNorm(dim)
+
+    def forward(self, x):
+        return ops.layernorm(x, self.body.weight, self.body.bias if self.body.with_bias else None)
+
+
+class FeedForward(nn.Module):
+    """GDFN, reference model/Restromer.py:79-104"""
+
+    def __init__(self, dim, ffn_expansion_factor, bias):
+        super().__init__()
+        hidden_features = int(dim * ffn_expansion_factor)
+        self.hidden_features = hidden_features
+        self.project_in = nn.Conv2d(dim, hidden_features * 2, kernel_size=1, bias=bias)
+        self.dwconv = nn.Conv2d(hidden_features * 2, hidden_features * 2, kernel_size=3, stride=1, padding=1,
+                                groups=hidden_features * 2, bias=bias)
+        self.project_out = nn.Conv2d(hidden_features, dim, kernel_size=1, bias=bias)
+
+    def forward(self, x):
+        return ops.feed_forward(x, self.hidden_features, *_flat(self.project_in), *_flat(self.dwconv),
+                                *_flat(self.project_out))
+
+
+class Attention(nn.Module):
+    """MDTA, reference model/Restromer.py:109-150"""
+
+    def __init__(self, dim, num_heads, bias):
+        super().__init__()
+        self.num_heads = num_heads
+        self.temperature = nn.Parameter(torch.ones(num_heads, 1, 1))
+        self.qkv = nn.Conv2d(dim, dim * 3, kernel_size=1, bias=bias)
+        self.qkv_dwconv = nn.Conv2d(dim * 3, dim * 3, kernel_size=3, stride=1, padding=1, groups=dim * 3, bias=bias)
+        self.project_out = nn.Conv2d(dim, dim, kernel_size=1, bias=bias)
+
+    def forward(self, x):
+        return ops.attention(x, self.num_heads, self.temperature, *_flat(self.qkv), *_flat(self.qkv_dwconv),
+                             *_flat(self.project_out))
+
+
+class TransformerBlock(nn.Module):
+    """reference model/Restromer.py:154-167: x += attn(norm1(x)); x += ffn(norm2(x)).
+    One fused call per direction (rst_block_fwd / rst_block_bwd)."""
+
+    def __init__(self, dim, num_heads, ffn_expansion_factor, bias, LayerNorm_type):
+        super().__init__()
+        self.norm1 = LayerNorm(dim, LayerNorm_type)
+        self.attn = Attention(dim, num_heads, bias)
+        self.norm2 = LayerNorm(dim, LayerNorm_type)
+        self.ffn = FeedForward(dim, ffn_expansion_factor, bias)
+
+    def _params(self):
+        n1, n2, a, f = self.norm1.body, self.norm2.body, self.attn, self.ffn
+        return {
+            "norm1_weight": n1.weight, "norm1_bias": n1.bias if n1.with_bias else None,
+            "temperature": a.temperature,
+            "qkv_weight": a.qkv.weight, "qkv_bias": a.qkv.bias,
+            "qkv_dw_weight": a.qkv_dwconv.weight, "qkv_dw_bias": a.qkv_dwconv.bias,
+            "proj_weight": a.project_out.weight, "proj_bias": a.project_out.bias,
+            "norm2_weight": n2.weight, "norm2_bias": n2.bias if n2.with_bias else None,
+            "pin_weight": f.project_in.weight, "pin_bias": f.project_in.bias,
+            "ffn_dw_weight": f.dwconv.weight, "ffn_dw_bias": f.dwconv.bias,
+            "pout_weight": f.project_out.weight, "pout_bias": f.project_out.bias,
+        }
+
+    def forward(self, x):
+        return ops.transformer_block(x, self.attn.num_heads, self.ffn.hidden_features, self._params())
+
+
+class OverlapPatchEmbed(nn.Module):
+    """3x3 embedding conv, reference model/Restromer.py:172-183"""
+
+    def __init__(self, in_c=3, embed_dim=48, bias=False):
+        super().__init__()
+        self.proj = nn.Conv2d(in_c, embed_dim, kernel_size=3, stride=1, padding=1, bias=bias)
+
+    def forward(self, x):
+        return self.proj(x)
+
+
+class _Permute(nn.Module):
+    """Parameter-free stand-in that keeps index 1 of ``body`` occupied, so the
+    conv stays ``body.0`` as in the reference's nn.Sequential."""
+
+    def __init__(self, fn):
+        super().__init__()
+        self._fn = fn
+
+    def forward(self, x):
+        return self._fn(x)
+
+
+class Downsample(nn.Module):
+    """conv3x3 C -> C/2, PixelUnshuffle(2); reference model/Restromer.py:188-200"""
+
+    def __init__(self, n_feat):
+        super().__init__()
+        self.body = nn.Sequential(
+            nn.Conv2d(n_feat, n_feat // 2, kernel_size=3, stride=1, padding=1, bias=False),
+            _Permute(ops.pixel_unshuffle2))
+
+    def forward(self, x):
+        return self.body(x)
+
+
+class Upsample(nn.Module):
+    """conv3x3 C -> 2C, PixelShuffle(2); reference model/Restromer.py:203-215"""
+
+    def __init__(self, n_feat):
+        super().__init__()
+        self.body = nn.Sequential(
+            nn.Conv2d(n_feat, n_feat * 2, kernel_size=3, stride=1, padding=1, bias=False),
+            _Permute(ops.pixel_shuffle2))
+
+    def forward(self, x):
+        return self.body(x)
+
+
+class Restormer(nn.Module):
+    """U-shaped x2 super-resolution network, reference model/Restromer.py:220-433."""
+
+    def __init__(self, inp_channels=4, out_channels=4, dim=12, num_blocks=[4, 6, 6, 8], num_refinement_blocks=4,
+                 heads=[1, 2, 4, 8], ffn_expansion_factor=1.25, bias=False, LayerNorm_type="WithBias",
+                 dual_pixel_task=False):
+        super().__init__()
+
+        def stage(width, n_heads, depth):
+            return nn.Sequential(*[TransformerBlock(dim=width, num_heads=n_heads, ffn_expansion_factor=ffn_expansion_factor,
+                                                    bias=bias, LayerNorm_type=LayerNorm_type) for _ in range(depth)])
+
+        w1, w2, w3, w4 = dim, dim * 2, dim * 4, dim * 8
+        # registration order = reference order (optimizer state is positional)
+        self.patch_embed = OverlapPatchEmbed(inp_channels, dim)
+        self.encoder_level1 = stage(w1, heads[0], num_blocks[0])
+        self.down1_2 = Downsample(w1)
+        self.encoder_level2 = stage(w2, heads[1], num_blocks[1])
+        self.down2_3 = Downsample(w2)
+        self.encoder_level3 = stage(w3, heads[2], num_blocks[2])
+        self.down3_4 = Downsample(w3)
+        self.latent = stage(w4, heads[3], num_blocks[3])
+        self.up4_3 = Upsample(w4)
+        self.reduce_chan_level3 = nn.Conv2d(w4, w3, kernel_size=1, bias=bias)
+        self.decoder_level3 = stage(w3, heads[2], num_blocks[2])
+        self.up3_2 = Upsample(w3)
+        self.reduce_chan_level2 = nn.Conv2d(w3, w2, kernel_size=1, bias=bias)
+        self.decoder_level2 = stage(w2, heads[1], num_blocks[1])
+        self.up2_1 = Upsample(w2)
+        self.decoder_level1 = stage(w2, heads[0], num_blocks[0])
+        self.refinement = stage(w2, heads[0], num_refinement_blocks)
+        self.output_upscale = Upsample(w2)
+        self.dual_pixel_task = dual_pixel_task
+        if self.dual_pixel_task:
+            self.skip_conv = nn.Conv2d(dim, w2, kernel_size=1, bias=bias)
+        self.output = nn.Conv2d(dim, out_channels, kernel_size=3, stride=1, padding=1, bias=bias)
+
+    def forward(self, inp_img):
+        if inp_img.dim() != 4:
+            raise RuntimeError(f"Restormer expects a 4-D NCHW tensor, got shape {tuple(inp_img.shape)}")
+        if inp_img.shape[-2] % 8 or inp_img.shape[-1] % 8:
+            raise RuntimeError(f"Restormer needs H and W divisible by 8, got {tuple(inp_img.shape[-2:])}")
+        e1_in = self.patch_embed(inp_img)
+        e1 = self.encoder_level1(e1_in)
+        e2 = self.encoder_level2(self.down1_2(e1))
+        e3 = self.encoder_level3(self.down2_3(e2))
+        lat = self.latent(self.down3_4(e3))
+
+        d3 = torch.cat([self.up4_3(lat), e3], 1)
+        d3 = self.decoder_level3(ops.conv1x1(d3, self.reduce_chan_level3.weight, self.reduce_chan_level3.bias))
+        d2 = torch.cat([self.up3_2(d3), e2], 1)
+        d2 = self.decoder_level2(ops.conv1x1(d2, self.reduce_chan_level2.weight, self.reduce_chan_level2.bias))
+        d1 = torch.cat([self.up2_1(d2), e1], 1)
+        d1 = self.refinement(self.decoder_level1(d1))
+        up = self.output_upscale(d1)
+
+        if self.dual_pixel_task:
+            # as written in the reference (model/Restromer.py:426-428)
+            return self.output(up + ops.conv1x1(e1_in, self.skip_conv.weight, self.skip_conv.bias))
+        base = F.interpolate(inp_img, scale_factor=2, mode="bilinear", align_corners=False)
+        return self.output(up) + base

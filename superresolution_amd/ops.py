@@ -1,0 +1,340 @@
+"""Host-side operators: torch tensors in, HIP kernels through the C ABI, autograd glue.
+
+torch is used for device memory (outputs, workspaces, saved buffers) and for the
+current stream; all arithmetic of these operators happens in
+librestormer_hip.so.  Every function requires fp32 tensors on a ROCm device and
+raises RuntimeError otherwise.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import BlockDesc, BlockGrads, BlockParams, PARAM_FIELDS, check
+
+
+# ----------------------------------------------------------------------------
+# plumbing
+# ----------------------------------------------------------------------------
+def _require(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: tensor is on {t.device}; this operator only runs on a ROCm GPU "
+                           "(there is no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name}: dtype {t.dtype} not supported (fp32 only)")
+    return t.contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+_workspaces: Dict[tuple, torch.Tensor] = {}
+
+
+def workspace(nbytes: int, device: torch.device) -> torch.Tensor:
+    """Grow-only scratch buffer, one per (device, stream).  Kernels enqueued on
+    one stream run in order, so consecutive operators may share it."""
+    key = (device.index, _stream())
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = None
+        _workspaces.pop(key, None)
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf
+
+
+def release_workspaces() -> None:
+    _workspaces.clear()
+
+
+def make_desc(B, C, H, W, heads, hidden, ln_with_bias, conv_bias) -> BlockDesc:
+    return BlockDesc(int(B), int(C), int(H), int(W), int(heads), int(hidden), int(bool(ln_with_bias)), int(bool(conv_bias)))
+
+
+def _fill(struct, tensors: Dict[str, Optional[torch.Tensor]]):
+    for name in PARAM_FIELDS:
+        t = tensors.get(name)
+        setattr(struct, name, None if t is None else t.data_ptr())
+    return struct
+
+
+# ----------------------------------------------------------------------------
+# LayerNorm (reference: LayerNorm.forward, model/Restromer.py:72-74)
+# ----------------------------------------------------------------------------
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        x = _require(x, "layernorm x")
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)
+        check(lib.rst_layernorm_fwd(_ptr(x), _ptr(weight), _ptr(bias), _ptr(y), B, C, H * W, _stream()), "rst_layernorm_fwd")
+        ctx.save_for_backward(x, weight)
+        ctx.with_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, weight = ctx.saved_tensors
+        dy = _require(dy, "layernorm dy")
+        B, C, H, W = x.shape
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(weight)
+        db = torch.empty_like(weight) if ctx.with_bias else None
+        nb = lib.rst_layernorm_bwd_workspace_bytes(B, C, H * W)
+        ws = workspace(nb, x.device)
+        check(lib.rst_layernorm_bwd(_ptr(x), _ptr(weight), int(ctx.with_bias), _ptr(dy), _ptr(dx), 0, _ptr(dw), _ptr(db),
+                                    B, C, H * W, _ptr(ws), ws.numel(), _stream()), "rst_layernorm_bwd")
+        return dx, dw, db
+
+
+def layernorm(x, weight, bias=None):
+    return _LayerNormFn.apply(x, weight, bias)
+
+
+# ----------------------------------------------------------------------------
+# 1x1 convolution (reference: nn.Conv2d(kernel_size=1), model/Restromer.py:309-311,326-328)
+# ----------------------------------------------------------------------------
+class _Conv1x1Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        x = _require(x, "conv1x1 x")
+        w = _require(weight, "conv1x1 weight")
+        B, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        y = torch.empty((B, Cout, H, W), dtype=x.dtype, device=x.device)
+        check(lib.rst_conv1x1_fwd(_ptr(x), _ptr(w), _ptr(bias), None, _ptr(y), B, Cin, Cout, H * W, _stream()), "rst_conv1x1_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        dy = _require(dy, "conv1x1 dy")
+        B, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dw = torch.empty_like(w)
+        db = torch.empty(Cout, dtype=x.dtype, device=x.device) if ctx.has_bias else None
+        nb = lib.rst_conv1x1_bwd_workspace_bytes(B, Cin, Cout, H * W)
+        ws = workspace(nb, x.device)
+        check(lib.rst_conv1x1_bwd(_ptr(x), _ptr(w), _ptr(dy), _ptr(dx), 0, _ptr(dw), _ptr(db), B, Cin, Cout, H * W,
+                                  _ptr(ws), ws.numel(), _stream()), "rst_conv1x1_bwd")
+        return dx, dw, db
+
+
+def conv1x1(x, weight, bias=None):
+    return _Conv1x1Fn.apply(x, weight, bias)
+
+
+# ----------------------------------------------------------------------------
+# depthwise 3x3 (reference: qkv_dwconv / dwconv, model/Restromer.py:87-95,116-124)
+# ----------------------------------------------------------------------------
+class _DwConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = _lib.load()
+        x = _require(x, "dwconv x")
+        w = _require(weight, "dwconv weight")
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)
+        check(lib.rst_dwconv3x3_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, C, H, W, _stream()), "rst_dwconv3x3_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        x, w = ctx.saved_tensors
+        dy = _require(dy, "dwconv dy")
+        B, C, H, W = x.shape
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(w)
+        db = torch.empty(C, dtype=x.dtype, device=x.device) if ctx.has_bias else None
+        nb = lib.rst_dwconv3x3_bwd_workspace_bytes(B, C, H, W)
+        ws = workspace(nb, x.device)
+        check(lib.rst_dwconv3x3_bwd(_ptr(x), _ptr(w), _ptr(dy), _ptr(dx), _ptr(dw), _ptr(db), B, C, H, W,
+                                    _ptr(ws), ws.numel(), _stream()), "rst_dwconv3x3_bwd")
+        return dx, dw, db
+
+
+def dwconv3x3(x, weight, bias=None):
+    return _DwConvFn.apply(x, weight, bias)
+
+
+# ----------------------------------------------------------------------------
+# PixelUnshuffle(2) / PixelShuffle(2) (reference: model/Restromer.py:196,211)
+# ----------------------------------------------------------------------------
+def _unshuffle_raw(x):
+    lib = _lib.load()
+    x = _require(x, "pixel_unshuffle x")
+    B, C, H, W = x.shape
+    if H % 2 or W % 2:
+        raise RuntimeError(f"pixel_unshuffle: H={H}, W={W} must be even")
+    y = torch.empty((B, C * 4, H // 2, W // 2), dtype=x.dtype, device=x.device)
+    check(lib.rst_pixel_unshuffle2(_ptr(x), _ptr(y), B, C, H, W, _stream()), "rst_pixel_unshuffle2")
+    return y
+
+
+def _shuffle_raw(x):
+    lib = _lib.load()
+    x = _require(x, "pixel_shuffle x")
+    B, C4, H, W = x.shape
+    if C4 % 4:
+        raise RuntimeError(f"pixel_shuffle: channels {C4} not divisible by 4")
+    y = torch.empty((B, C4 // 4, H * 2, W * 2), dtype=x.dtype, device=x.device)
+    check(lib.rst_pixel_shuffle2(_ptr(x), _ptr(y), B, C4 // 4, H, W, _stream()), "rst_pixel_shuffle2")
+    return y
+
+
+class _PixelUnshuffleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return _unshuffle_raw(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _shuffle_raw(dy)
+
+
+class _PixelShuffleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return _shuffle_raw(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _unshuffle_raw(dy)
+
+
+def pixel_unshuffle2(x):
+    return _PixelUnshuffleFn.apply(x)
+
+
+def pixel_shuffle2(x):
+    return _PixelShuffleFn.apply(x)
+
+
+# ----------------------------------------------------------------------------
+# composite operators: MDTA, GDFN, TransformerBlock
+# ----------------------------------------------------------------------------
+ATTN_FIELDS = ("temperature", "qkv_weight", "qkv_bias", "qkv_dw_weight", "qkv_dw_bias", "proj_weight", "proj_bias")
+FFN_FIELDS = ("pin_weight", "pin_bias", "ffn_dw_weight", "ffn_dw_bias", "pout_weight", "pout_bias")
+NORM_FIELDS = ("norm1_weight", "norm1_bias", "norm2_weight", "norm2_bias")
+
+
+def _composite(kind: str, fields: Sequence[str]):
+    """Build an autograd Function for one of the composite C entry points.
+
+    forward(x, heads, hidden, ln_with_bias, conv_bias, *params) where params
+    follow `fields` (None for absent biases)."""
+    fwd_name, bwd_name = f"rst_{kind}_fwd", f"rst_{kind}_bwd"
+
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, heads, hidden, ln_with_bias, conv_bias, *params):
+            lib = _lib.load()
+            x = _require(x, f"{kind} x")
+            B, C, H, W = x.shape
+            if C % heads:
+                raise RuntimeError(f"{kind}: channels {C} not divisible by heads {heads}")
+            tensors = {n: (None if p is None else _require(p, f"{kind} {n}")) for n, p in zip(fields, params)}
+            desc = make_desc(B, C, H, W, heads, hidden, ln_with_bias, conv_bias)
+            par = _fill(BlockParams(), tensors)
+            need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p is not None and p.requires_grad for p in params))
+            saved = None
+            if need_grad:
+                nbytes = getattr(lib, f"rst_{kind}_saved_bytes")(ctypes.byref(desc))
+                saved = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+            ws = workspace(getattr(lib, f"rst_{kind}_workspace_bytes")(ctypes.byref(desc)), x.device)
+            y = torch.empty_like(x)
+            fn = getattr(lib, fwd_name)
+            if kind == "block":
+                st = fn(ctypes.byref(desc), ctypes.byref(par), _ptr(x), _ptr(y), _ptr(saved), _ptr(ws), ws.numel(), _stream())
+            else:
+                st = fn(ctypes.byref(desc), ctypes.byref(par), _ptr(x), None, _ptr(y), _ptr(saved), _ptr(ws), ws.numel(), _stream())
+            check(st, fwd_name)
+            if need_grad:
+                ctx.desc_args = (B, C, H, W, heads, hidden, ln_with_bias, conv_bias)
+                ctx.present = [p is not None for p in params]
+                ctx.save_for_backward(x, saved, *[tensors[n] for n in fields if tensors[n] is not None])
+            return y
+
+        @staticmethod
+        def backward(ctx, dy):
+            lib = _lib.load()
+            x, saved, *plist = ctx.saved_tensors
+            dy = _require(dy, f"{kind} dy")
+            desc = make_desc(*ctx.desc_args)
+            it = iter(plist)
+            tensors = {n: (next(it) if present else None) for n, present in zip(fields, ctx.present)}
+            par = _fill(BlockParams(), tensors)
+            grads = {n: (None if t is None else torch.empty_like(t)) for n, t in tensors.items()}
+            gr = _fill(BlockGrads(), grads)
+            ws = workspace(getattr(lib, f"rst_{kind}_bwd_workspace_bytes")(ctypes.byref(desc)), x.device)
+            dx = torch.empty_like(x)
+            fn = getattr(lib, bwd_name)
+            if kind == "block":
+                st = fn(ctypes.byref(desc), ctypes.byref(par), _ptr(x), _ptr(dy), _ptr(saved), _ptr(dx), ctypes.byref(gr),
+                        _ptr(ws), ws.numel(), _stream())
+            else:
+                st = fn(ctypes.byref(desc), ctypes.byref(par), _ptr(x), _ptr(dy), _ptr(saved), _ptr(dx), 0, ctypes.byref(gr),
+                        _ptr(ws), ws.numel(), _stream())
+            check(st, bwd_name)
+            return (dx, None, None, None, None) + tuple(grads[n] for n in fields)
+
+    Fn.__name__ = f"_{kind.capitalize()}Fn"
+    return Fn
+
+
+_AttentionFn = _composite("attention", ATTN_FIELDS)
+_FfnFn = _composite("ffn", FFN_FIELDS)
+_BlockFn = _composite("block", PARAM_FIELDS)
+
+
+def attention(x, heads, temperature, qkv_weight, qkv_bias, qkv_dw_weight, qkv_dw_bias, proj_weight, proj_bias):
+    """MDTA (reference: Attention.forward, model/Restromer.py:127-150)."""
+    return _AttentionFn.apply(x, heads, 1, True, qkv_bias is not None,
+                              temperature, qkv_weight, qkv_bias, qkv_dw_weight, qkv_dw_bias, proj_weight, proj_bias)
+
+
+def feed_forward(x, hidden, pin_weight, pin_bias, dw_weight, dw_bias, pout_weight, pout_bias):
+    """GDFN (reference: FeedForward.forward, model/Restromer.py:99-104)."""
+    return _FfnFn.apply(x, 1, hidden, True, pin_bias is not None,
+                        pin_weight, pin_bias, dw_weight, dw_bias, pout_weight, pout_bias)
+
+
+def transformer_block(x, heads, hidden, params: Dict[str, Optional[torch.Tensor]]):
+    """TransformerBlock (reference: model/Restromer.py:163-167).  `params` maps
+    the names in PARAM_FIELDS to tensors (None for absent biases)."""
+    ln_with_bias = params.get("norm1_bias") is not None
+    conv_bias = params.get("qkv_bias") is not None
+    return _BlockFn.apply(x, heads, hidden, ln_with_bias, conv_bias, *[params.get(n) for n in PARAM_FIELDS])
+
+
+def block_forward_inplace(x, heads, hidden, params: Dict[str, Optional[torch.Tensor]]):
+    """Inference-only in-place block update (no autograd, no saved buffer)."""
+    lib = _lib.load()
+    x = _require(x, "block x")
+    B, C, H, W = x.shape
+    tensors = {n: (None if params.get(n) is None else _require(params[n], n)) for n in PARAM_FIELDS}
+    desc = make_desc(B, C, H, W, heads, hidden, tensors["norm1_bias"] is not None, tensors["qkv_bias"] is not None)
+    par = _fill(BlockParams(), tensors)
+    ws = workspace(lib.rst_block_workspace_bytes(ctypes.byref(desc)), x.device)
+    check(lib.rst_block_fwd(ctypes.byref(desc), ctypes.byref(par), _ptr(x), _ptr(x), None, _ptr(ws), ws.numel(), _stream()),
+          "rst_block_fwd")
+    return x
