@@ -255,7 +255,7 @@ def _composite(kind: str, fields: Sequence[str]):
             tensors = {n: (None if p is None else _require(p, f"{kind} {n}")) for n, p in zip(fields, params)}
             desc = make_desc(B, C, H, W, heads, hidden, ln_with_bias, conv_bias)
             par = _fill(BlockParams(), tensors)
-            need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p is not None and p.requires_grad for p in params))
+            need_grad = any(ctx.needs_input_grad)   # grad mode is off inside Function.forward
             saved = None
             if need_grad:
                 nbytes = getattr(lib, f"rst_{kind}_saved_bytes")(ctypes.byref(desc))
