@@ -206,6 +206,17 @@ int rst_block_bwd(const rst_block_desc* desc, const rst_block_params* params,
                   float* dx, rst_block_grads* grads,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------- */
+/* Per-kernel timing aid.  No counterpart in the reference (it has no timing   */
+/* code on this path); used by bench.py for the roofline numbers.  Between     */
+/* begin and end every kernel launch of this library is bracketed by HIP       */
+/* events on its stream; end waits for them and writes a JSON object           */
+/* {label: {launches, ms, flops, bytes}} (algorithmic FLOPs / bytes) into json. */
+/* Process-wide, not for concurrent use; adds two event records per launch.    */
+/* ------------------------------------------------------------------------- */
+int rst_profile_begin(void);
+int rst_profile_end(char* json, size_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

@@ -198,6 +198,7 @@ int attn_bwd_small_launch(const float* P, const float* wo, const float* attn, co
                           const float* nk, const float* temperature, float* Eq, float* Dq, float* Dk, float* dGG,
                           float* dtemp_row, float* dtemp_b, float* dwo_b, int B, int C, int heads, int c,
                           hipStream_t stream) {
+    ProfScope prof(stream, "attn_bwd_small", 6.0 * B * C * C * c, 4.0 * B * (3.0 * C * C + 6.0 * heads * c * c));
     {
         const size_t lds = (size_t)4 * c * sizeof(float);
         RST_REQUIRE(lds <= 64 * 1024, "attention: channels per head %d too large", c);
@@ -228,6 +229,7 @@ int attn_softmax_launch(const float* gram_partial, const float* sqq_partial, con
     const size_t lds = (size_t)(c + 4 * c) * sizeof(float);
     RST_REQUIRE(lds <= 64 * 1024, "attention: channels per head %d too large", c);
     dim3 grid((unsigned)cdiv(c, 4), (unsigned)(B * heads));
+    ProfScope prof(stream, "attn_softmax", (double)B * heads * c * c * (splits + 8.0), 4.0 * B * heads * c * c * (splits + 1.0));
     hipLaunchKernelGGL(attn_softmax_kernel, grid, dim3(256), lds, stream, gram_partial, sqq_partial, sqk_partial,
                        temperature, attn, ghat, nq, nk, heads, c, splits);
     RST_LAUNCH_CHECK();
@@ -241,6 +243,7 @@ int attn_fold_launch(const float* wo, const float* attn, float* mfold, int B, in
         RST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fold_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((unsigned)cdiv(C, 16), (unsigned)heads, (unsigned)B);
+    ProfScope prof(stream, "attn_fold", 2.0 * B * C * C * c, 4.0 * B * (2.0 * C * C + (double)heads * c * c));
     hipLaunchKernelGGL(attn_fold_kernel, grid, dim3(256), lds, stream, wo, attn, mfold, C, heads, c);
     RST_LAUNCH_CHECK();
     return RST_OK;

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <string>
 
 #include "../../include/restormer_hip.h"
@@ -57,6 +58,18 @@ inline int fail(int code, const char* fmt, ...) {
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline int64_t round_up(int64_t a, int64_t b) { return cdiv(a, b) * b; }
+
+// ---- optional per-kernel timing (prof.hip) -------------------------------------
+bool prof_enabled();
+class ProfScope {
+public:
+    ProfScope(hipStream_t s, const char* label, double flops, double bytes);
+    ~ProfScope();
+    ProfScope(const ProfScope&) = delete;
+    ProfScope& operator=(const ProfScope&) = delete;
+private:
+    hipStream_t stream_; const char* label_; double flops_, bytes_; bool on_; void* e0_;
+};
 
 // ---- device helpers ---------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -270,6 +270,7 @@ int dwconv_fwd_launch(const DwArgs& a, hipStream_t stream) {
     const int64_t total = (int64_t)a.B * a.C * sx * sy;
     const int64_t grid = cdiv(total, 256);
     RST_REQUIRE(grid < (1ll << 31), "dwconv3x3: grid too large");
+    ProfScope prof(stream, "dwconv3x3", 18.0 * a.B * a.C * a.H * a.W, 2.0 * 4 * a.B * a.C * a.H * a.W);
     if (dw_vec_ok(a.W, a.x_bstride, a.y_bstride, a.x, a.y))
         hipLaunchKernelGGL(dwconv_fwd_kernel<true>, dim3((unsigned)grid), dim3(256), 0, stream, a, sx, sy, total);
     else
@@ -284,6 +285,8 @@ int dwconv_gate_fwd_launch(const GateArgs& a, hipStream_t stream) {
     const int64_t total = (int64_t)a.B * a.hidden * sx * sy;
     const int64_t grid = cdiv(total, 256);
     RST_REQUIRE(grid < (1ll << 31), "dwconv_gate: grid too large");
+    ProfScope prof(stream, "dwconv3x3_gate", 46.0 * a.B * a.hidden * a.H * a.W,
+                   4.0 * a.B * a.hidden * a.H * a.W * (3.0 + (a.d ? 2.0 : 0.0)));
     const bool vec = dw_vec_ok(a.W, a.u_bstride, a.g_bstride, a.u, a.gout) &&
                      (a.d == nullptr || (aligned16(a.d) && a.d_bstride % 4 == 0));
     if (vec) hipLaunchKernelGGL(dwconv_gate_fwd_kernel<true>, dim3((unsigned)grid), dim3(256), 0, stream, a, sx, sy, total);
@@ -294,6 +297,7 @@ int dwconv_gate_fwd_launch(const GateArgs& a, hipStream_t stream) {
 
 int gate_bwd_launch(const float* dg, const float* d, float* dd, int B, int hidden, int64_t hw, hipStream_t stream) {
     const int64_t total = (int64_t)B * hidden * hw;
+    ProfScope prof(stream, "gate_bwd", 20.0 * total, 4.0 * 5 * total);
     hipLaunchKernelGGL(gate_bwd_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, dg, d, dd,
                        (int64_t)hidden * hw, total);
     RST_LAUNCH_CHECK();
@@ -322,6 +326,7 @@ int dwconv_bwd_weight_launch(const float* x, int64_t x_bstride, const float* dy,
     const int sx = (int)cdiv(W, 4), sy = (int)cdiv(H, DW_ROWS);
     float* partial = static_cast<float*>(ws);
     dim3 grid(C, splits);
+    ProfScope prof(stream, "dwconv3x3_bwd_weight", 20.0 * B * C * H * W, 2.0 * 4 * B * C * H * W);
     if (dw_vec_ok(W, x_bstride, dy_bstride, x, dy))
         hipLaunchKernelGGL(dwconv_bwd_weight_kernel<true>, grid, dim3(256), 0, stream, x, x_bstride, dy, dy_bstride, partial, B, C, H, W, sx, sy);
     else

@@ -190,6 +190,9 @@ int gemm_nn_launch(const GemmNN& g, hipStream_t stream) {
     RST_REQUIRE(gx < (1ll << 31), "gemm_nn: grid too large");
     const bool vecx = (g.N % 4 == 0) && (g.ldx % 4 == 0) && (g.x_s1 % 4 == 0) && (g.x_s2 % 4 == 0) && aligned16(g.X);
     dim3 grid((unsigned)gx, (unsigned)(g.nb1 * g.nb2)), blk(256);
+    const double nb = (double)g.nb1 * g.nb2;
+    ProfScope prof(stream, "gemm_nn", 2.0 * g.M * g.K * g.N * nb,
+                   4.0 * nb * g.N * (g.K + g.M * (1.0 + (g.R ? 1.0 : 0.0) + (g.accumulate ? 1.0 : 0.0))));
 #define GN_CASE(MTV)                                                                          \
     case MTV:                                                                                 \
         if (vecx) hipLaunchKernelGGL((gemm_nn_kernel<MTV, true>), grid, blk, 0, stream, g, mblocks);  \

@@ -261,6 +261,9 @@ int gemm_nt_launch(GemmNT g, const NtPlan& p, hipStream_t stream) {
     const size_t red = (size_t)WK * WR * WC * p.d1.T * p.d2.T * 64 * 4 * sizeof(float);
     if (WK > 1 && red > lds) lds = red;
     dim3 gd((unsigned)grid), blk(256);
+    const double nb = (double)g.nb1 * g.nb2;
+    ProfScope prof(stream, "gemm_nt_splitk", 2.0 * g.M1 * g.M2 * g.N * nb,
+                   4.0 * nb * ((double)(g.M1 + g.M2) * g.N + (double)p.splits * g.M1 * g.M2));
 #define NT_CASE(a, b)                                                                                         \
     if (p.d1.T == a && p.d2.T == b) {                                                                         \
         if (vec) hipLaunchKernelGGL((gemm_nt_kernel<a, b, true>), gd, blk, lds, stream, g, WR, WC, p.d1.blocks, p.d2.blocks);  \
@@ -279,6 +282,8 @@ int gemm_nt_launch(GemmNT g, const NtPlan& p, hipStream_t stream) {
 int reduce_slabs_launch(const float* partial, float* out, int64_t elems, int groups, int slabs_per_group,
                         int accumulate, hipStream_t stream) {
     dim3 gd((unsigned)cdiv(elems, 256), (unsigned)groups), blk(256);
+    ProfScope prof(stream, "reduce_slabs", (double)elems * groups * slabs_per_group,
+                   4.0 * elems * groups * (slabs_per_group + 1.0));
     hipLaunchKernelGGL(reduce_slabs_kernel, gd, blk, 0, stream, partial, out, elems, slabs_per_group, accumulate);
     RST_LAUNCH_CHECK();
     return RST_OK;

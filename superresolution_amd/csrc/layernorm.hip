@@ -290,6 +290,7 @@ int layernorm_fwd_launch(const float* x, const float* weight, const float* bias,
     RST_REQUIRE(grid > 0 && grid < (1ll << 31), "layernorm: grid out of range");
     const size_t lds = (size_t)2 * p.waves * 64 * p.vec * sizeof(float);
     dim3 blk(p.waves * 64);
+    ProfScope prof(stream, "layernorm_fwd", 8.0 * B * C * N, 2.0 * 4 * B * C * N);
 #define LN_FWD(V, CP) hipLaunchKernelGGL((ln_fwd_kernel<V, CP>), dim3((unsigned)grid), blk, lds, stream, x, weight, bias, y, C, N, tps)
     if (p.vec == 4 && p.cpt == 12) LN_FWD(4, 12);
     else if (p.vec == 4 && p.cpt == 24) LN_FWD(4, 24);
@@ -321,6 +322,7 @@ int layernorm_bwd_launch(const float* x, const float* weight, int with_bias, con
     const size_t lds = (size_t)2 * p.waves * 64 * p.vec * sizeof(float);
     dim3 blk(p.waves * 64);
     float* partial = static_cast<float*>(ws);
+    ProfScope prof(stream, "layernorm_bwd", 20.0 * B * C * N, (addend ? 4.0 : 3.0) * 4 * B * C * N);
 #define LN_BWD(V, CP) hipLaunchKernelGGL((ln_bwd_kernel<V, CP>), dim3(grid), blk, lds, stream, x, weight, with_bias, dy, addend, dx, partial, C, N, tps, total)
     if (p.vec == 4 && p.cpt == 12) LN_BWD(4, 12);
     else if (p.vec == 1 && p.cpt == 12) LN_BWD(1, 12);

@@ -37,6 +37,7 @@ int rowsum_launch(const float* x, int64_t x_bstride, float* out, int B, int rows
     RST_REQUIRE(B > 0 && rows > 0 && N > 0 && B <= 65535, "rowsum: bad shape");
     if (ws == nullptr || ws_bytes < rowsum_ws_bytes(B, rows, N)) return fail(RST_ERR_WORKSPACE, "rowsum: workspace too small");
     float* partial = static_cast<float*>(ws);
+    ProfScope prof(stream, "rowsum", (double)B * rows * N, 4.0 * B * rows * N);
     hipLaunchKernelGGL(rowsum_partial_kernel, dim3(rows, B), dim3(256), 0, stream, x, x_bstride, partial, rows, N);
     RST_LAUNCH_CHECK();
     hipLaunchKernelGGL(rowsum_final_kernel, dim3((unsigned)cdiv(rows, 128)), dim3(128), 0, stream, partial, out, rows, B);

@@ -61,6 +61,7 @@ int pixel_shuffle2_launch(bool shuffle, const float* src, float* dst, int B, int
     RST_REQUIRE(grid < (1ll << 31), "pixel_shuffle: grid too large");
     const bool vec = (W % 4 == 0) && aligned16(src) && aligned16(dst);
     dim3 gd((unsigned)grid), blk(256);
+    ProfScope prof(stream, shuffle ? "pixel_shuffle2" : "pixel_unshuffle2", 0.0, 2.0 * 4 * 4 * B * C * H * W);
     if (shuffle) {
         if (vec) hipLaunchKernelGGL((pixel_shuffle2_kernel<true, true>), gd, blk, 0, stream, src, dst, C, H, W, total);
         else     hipLaunchKernelGGL((pixel_shuffle2_kernel<true, false>), gd, blk, 0, stream, src, dst, C, H, W, total);

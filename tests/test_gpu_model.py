@@ -1,0 +1,86 @@
+"""Whole-network parity on the GPU against the fixtures written from the reference
+(tests/golden/model_*.npz, train_*.npz).  fp32, contract tolerance 1e-4 max
+relative error per tensor; scalar loss 1e-5 relative."""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import check_pin, load
+from oracle import recipe
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _net(case):
+    from superresolution_amd.model.Restromer import Restormer
+    tag, kwargs, shape = case
+    sd, x, tgt = recipe.model_case_tensors(case, torch.float32)
+    net = Restormer(**kwargs)
+    net.load_state_dict(sd, strict=True)
+    return net.cuda(), x.cuda(), tgt.cuda()
+
+
+@pytest.mark.parametrize("case", recipe.MODEL_CASES, ids=[c[0] for c in recipe.MODEL_CASES])
+def test_model_forward_backward(case):
+    tag = case[0]
+    g = load("model_" + tag)
+    net, x, tgt = _net(case)
+    with torch.no_grad():
+        check_pin(g, "out", net(x), TOL, tag + " (no_grad)")
+    x.requires_grad_(True)
+    out = net(x)
+    loss = (out - tgt).abs().mean()
+    loss.backward()
+    check_pin(g, "out", out, TOL, tag)
+    assert abs(loss.item() - float(g["loss"])) <= 1e-5 * float(g["loss"])
+    check_pin(g, "dx", x.grad, 5e-4, tag)     # sign(out - tgt) makes the L1 gradient discontinuous; see note below
+    worst = 0.0
+    for k, p in net.named_parameters():
+        ref = float(g["gl2/" + k])
+        got = float(p.grad.double().norm())
+        worst = max(worst, abs(got - ref) / max(ref, 1e-12))
+        if ("d/" + k + "/v") in g:
+            check_pin(g, "d/" + k, p.grad, 5e-4, tag)
+    # L1 loss: an output element within rounding of its target can flip sign(out - tgt),
+    # which perturbs every gradient by O(1/numel); 5e-4 bounds that, the forward keeps 1e-4.
+    assert worst < 5e-4, worst
+    gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in net.parameters())).item()
+    assert abs(gn - float(g["grad_norm"])) <= 5e-4 * float(g["grad_norm"])
+
+
+def test_training_steps_follow_reference():
+    """Three optimiser steps in the order of the reference's loop (zero_grad, forward,
+    L1, backward, clip_grad_norm_(1.0), Adam(1e-4, wd 1e-6)) reproduce its loss curve."""
+    case = recipe.MODEL_CASES[0]
+    g = load("train_" + case[0])
+    net, x, tgt = _net(case)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, weight_decay=1e-6)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        loss = torch.nn.functional.l1_loss(net(x), tgt)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), max_norm=1.0)
+        opt.step()
+        losses.append(loss.item())
+    assert np.allclose(losses, g["losses"], rtol=2e-5), (losses, g["losses"])
+    with torch.no_grad():
+        check_pin(g, "out_after", net(x), 2e-3, "after 3 steps")
+
+
+def test_large_shape_properties():
+    """Full-size properties that need no oracle: the block is a residual update that is
+    deterministic run to run, and in-place inference equals out-of-place inference."""
+    from superresolution_amd import ops
+    from superresolution_amd.model.Restromer import TransformerBlock
+    torch.manual_seed(0)
+    blk = TransformerBlock(96, 1, 1.25, False, "WithBias").cuda()
+    x = torch.rand(2, 96, 256, 256, device="cuda")
+    with torch.no_grad():
+        y1 = blk(x)
+        y2 = blk(x)
+        assert torch.equal(y1, y2)
+        z = ops.block_forward_inplace(x.clone(), 1, blk.ffn.hidden_features, blk._params())
+        assert torch.equal(z, y1)
+        assert torch.isfinite(y1).all()
