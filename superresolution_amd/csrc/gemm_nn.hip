@@ -161,8 +161,8 @@ gemm_nn_kernel(GemmNN g, int mblocks) {
     }
 }
 
-// Pick the number of 16-row tiles per block: least padded rows first, then the
-// fewest blocks along M (each M-block re-reads the pixel stream).
+// Pick the number of 16-row tiles per block: fewest blocks along M first (every
+// M-block re-reads the pixel stream), then the least padded rows.
 static int pick_mt(int M) {
     static const int cand[] = {9, 8, 6, 4, 3, 2, 1};
     int best = 1;
@@ -171,18 +171,25 @@ static int pick_mt(int M) {
         const int bm = 16 * mt;
         const int64_t blocks = cdiv(M, bm);
         const int64_t pad = blocks * bm;
-        if (pad < best_pad || (pad == best_pad && blocks < best_blocks)) {
+        if (blocks < best_blocks || (blocks == best_blocks && pad < best_pad)) {
             best = mt; best_pad = pad; best_blocks = blocks;
         }
     }
     return best;
 }
 
+int gemm_nn_res_try(const GemmNN& g, hipStream_t stream, bool* launched);
+
 int gemm_nn_launch(const GemmNN& g, hipStream_t stream) {
     RST_REQUIRE(g.M > 0 && g.K > 0 && g.N > 0 && g.nb1 > 0 && g.nb2 > 0,
                 "gemm_nn: empty problem (M=%d K=%d N=%lld batch=%dx%d)", g.M, g.K, (long long)g.N, g.nb1, g.nb2);
     RST_REQUIRE(g.A && g.X && g.Y, "gemm_nn: null operand");
     RST_REQUIRE((int64_t)g.nb1 * g.nb2 <= 65535, "gemm_nn: batch %dx%d exceeds grid.y", g.nb1, g.nb2);
+    {
+        bool done = false;
+        RST_TRY(gemm_nn_res_try(g, stream, &done));
+        if (done) return RST_OK;
+    }
     const int mt = pick_mt(g.M);
     const int mblocks = (int)cdiv(g.M, 16 * mt);
     const int64_t ntiles = cdiv(g.N, GN_BN);

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Per-shape timing of single operators through the C ABI (development aid).
+usage: python tools/bench_ops.py [gemm|dw|ln|gram|all]"""
+import ctypes
+import sys
+import os
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from superresolution_amd import _lib, ops  # noqa: E402
+
+lib = _lib.load()
+S = torch.cuda.current_stream().cuda_stream
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3     # us
+
+
+# (label, M, K, pixels per sample, residual)
+B = 16
+GEMM = [
+    ("L1 qkv   144x48 ", 144, 48, 65536, False), ("L1 av     48x48 ", 48, 48, 65536, True),
+    ("L1 pin   120x48 ", 120, 48, 65536, False), ("L1 pout   48x60 ", 48, 60, 65536, True),
+    ("D1 qkv   288x96 ", 288, 96, 65536, False), ("D1 av     96x96 ", 96, 96, 65536, True),
+    ("D1 pin   240x96 ", 240, 96, 65536, False), ("D1 pout   96x120", 96, 120, 65536, True),
+    ("L2 qkv   288x96 ", 288, 96, 16384, False), ("L2 av     96x96 ", 96, 96, 16384, True),
+    ("L2 pin   240x96 ", 240, 96, 16384, False), ("L2 pout   96x120", 96, 120, 16384, True),
+    ("L3 qkv   576x192", 576, 192, 4096, False), ("L3 av    192x192", 192, 192, 4096, True),
+    ("L3 pin   480x192", 480, 192, 4096, False), ("L3 pout  192x240", 192, 240, 4096, True),
+    ("L4 qkv  1152x384", 1152, 384, 1024, False), ("L4 av    384x384", 384, 384, 1024, True),
+    ("L4 pin   960x384", 960, 384, 1024, False), ("L4 pout  384x480", 384, 480, 1024, True),
+]
+
+
+def bench_gemm(only=None):
+    tot = 0.0
+    for label, M, K, N, res in GEMM:
+        if only and only not in label:
+            continue
+        x = torch.randn(B, K, N, device="cuda")
+        w = torch.randn(M, K, device="cuda") / K ** 0.5
+        r = torch.randn(B, M, N, device="cuda") if res else None
+        y = torch.empty(B, M, N, device="cuda")
+        fn = lambda: lib.rst_conv1x1_fwd(x.data_ptr(), w.data_ptr(), None, r.data_ptr() if res else None, y.data_ptr(), B, K, M, N, S)
+        us = timeit(fn)
+        fl = 2.0 * M * K * N * B
+        by = 4.0 * N * B * (K + M * (2 if res else 1))
+        mult = {"L1": 4, "D1": 8, "L2": 12, "L3": 12, "L4": 8}[label[:2]]
+        tot += us * mult
+        print(f"{label}  {us:8.1f} us  {fl / us / 1e6:6.1f} TFLOP/s  {by / us / 1e3:7.1f} GB/s   x{mult} = {us * mult / 1e3:6.2f} ms")
+    print(f"gemm_nn total per forward: {tot / 1e3:.2f} ms")
+
+
+def bench_dw():
+    for label, C, H in [("L1 qkv 144", 144, 256), ("D1 qkv 288", 288, 256), ("L2 288", 288, 128), ("L3 576", 576, 64), ("L4 1152", 1152, 32)]:
+        x = torch.randn(B, C, H, H, device="cuda")
+        w = torch.randn(C, 9, device="cuda")
+        y = torch.empty_like(x)
+        us = timeit(lambda: lib.rst_dwconv3x3_fwd(x.data_ptr(), w.data_ptr(), None, y.data_ptr(), B, C, H, H, S))
+        print(f"dwconv {label} {us:8.1f} us {2 * 4.0 * x.numel() / us / 1e3:7.1f} GB/s")
+
+
+def bench_ln():
+    for C, H in [(48, 256), (96, 256), (96, 128), (192, 64), (384, 32)]:
+        x = torch.randn(B, C, H, H, device="cuda")
+        w = torch.randn(C, device="cuda"); b = torch.randn(C, device="cuda")
+        y = torch.empty_like(x)
+        us = timeit(lambda: lib.rst_layernorm_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), B, C, H * H, S))
+        print(f"layernorm C={C} H={H} {us:8.1f} us {2 * 4.0 * x.numel() / us / 1e3:7.1f} GB/s")
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("gemm", "all"):
+        bench_gemm(sys.argv[2] if len(sys.argv) > 2 else None)
+    if what in ("dw", "all"):
+        bench_dw()
+    if what in ("ln", "all"):
+        bench_ln()
