@@ -179,6 +179,7 @@ static int pick_mt(int M) {
 }
 
 int gemm_nn_res_try(const GemmNN& g, hipStream_t stream, bool* launched);
+int gemm_nn_dma_try(const GemmNN& g, hipStream_t stream, bool* launched);
 
 int gemm_nn_launch(const GemmNN& g, hipStream_t stream) {
     RST_REQUIRE(g.M > 0 && g.K > 0 && g.N > 0 && g.nb1 > 0 && g.nb2 > 0,
@@ -188,6 +189,8 @@ int gemm_nn_launch(const GemmNN& g, hipStream_t stream) {
     {
         bool done = false;
         RST_TRY(gemm_nn_res_try(g, stream, &done));
+        if (done) return RST_OK;
+        RST_TRY(gemm_nn_dma_try(g, stream, &done));
         if (done) return RST_OK;
     }
     const int mt = pick_mt(g.M);

@@ -27,23 +27,24 @@ typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 template <int MT, int KS, bool RES>
-__global__ void __launch_bounds__(256, 1)
+__global__ void __launch_bounds__(512, 2)
 gemm_nn_res_kernel(GemmNN g, int mblocks, int ntiles, int64_t total_tiles, int groups) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KROWS = 4 * KS;            // == K, checked by the launcher
     constexpr int BUF = KROWS * GR_BN;
-    float* scratch = smem + 2 * BUF;          // [4 waves][2 slots][16][GR_SCR_LD]
+    float* scratch = smem + 2 * BUF;          // [8 waves][2 slots][16][GR_SCR_LD]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lm = lane & 15, kk = lane >> 4;
-    const int wn0 = wave * 32;
+    const int wn0 = (wave & 3) * 32;          // pixel quarter of this wave
+    const int mg = wave >> 2;                 // which half of the block's rows
     // blocks 8 apart share an XCD: put the M-blocks of one pixel range there
     const int bid = blockIdx.x;
     const int rem = bid % (8 * mblocks);
     const int mb = rem / 8;
     const int j = (bid / (8 * mblocks)) * 8 + (rem % 8);
     const int64_t t_begin = total_tiles * j / groups, t_end = total_tiles * (j + 1) / groups;
-    const int m0 = mb * 16 * MT;
+    const int m0 = mb * 32 * MT + mg * 16 * MT;   // first row of this wave
 
     auto issue_tile = [&](int64_t t, int buf) {
         const int64_t bb = t / ntiles;
@@ -52,7 +53,7 @@ gemm_nn_res_kernel(GemmNN g, int mblocks, int ntiles, int64_t total_tiles, int g
         const float* Xb = g.X + (int64_t)b1 * g.x_s1 + (int64_t)b2 * g.x_s2 + n0;
         const int col = (lane & 31) * 4;
         const bool ok = n0 + col < g.N;       // N % 4 == 0
-        for (int p = wave; 2 * p < g.K; p += 4) {
+        for (int p = wave; 2 * p < g.K; p += 8) {
             const int row = 2 * p + (lane >> 5);
             float* dst = smem + buf * BUF + 2 * p * GR_BN;          // wave-uniform base
             if (ok)
@@ -79,14 +80,15 @@ gemm_nn_res_kernel(GemmNN g, int mblocks, int ntiles, int64_t total_tiles, int g
             constexpr int K = 4 * KS;
             constexpr int SLD = K + 1;
             float* st = scratch;
-            static_assert(16 * SLD <= 8 * 16 * GR_SCR_LD, "staging area too small");
+            static_assert(16 * SLD <= 16 * 16 * GR_SCR_LD, "staging area too small");
+            const int mblk = mb * 32 * MT;
 #pragma unroll 1
-            for (int i = 0; i < MT; ++i) {
+            for (int i2 = 0; i2 < 2 * MT; ++i2) {
                 __syncthreads();
-                for (int e = tid; e < 16 * K; e += 256) {
+                for (int e = tid; e < 16 * K; e += 512) {
                     int r, k;
                     if (g.transA) { k = e >> 4; r = e & 15; } else { r = e / K; k = e - r * K; }
-                    const int m = m0 + 16 * i + r;
+                    const int m = mblk + 16 * i2 + r;
                     float v = 0.f;
                     if (m < g.M) v = g.transA ? Ab[(int64_t)k * g.lda + m] : Ab[(int64_t)m * g.lda + k];
                     st[r * SLD + k] = v;
@@ -95,7 +97,7 @@ gemm_nn_res_kernel(GemmNN g, int mblocks, int ntiles, int64_t total_tiles, int g
                 // static register index needs a compile-time i: dispatch over the unrolled copy
 #pragma unroll
                 for (int ii = 0; ii < MT; ++ii) {
-                    if (ii == i) {
+                    if (mg * MT + ii == i2) {
 #pragma unroll
                         for (int s = 0; s < KS; ++s) wreg[ii][s] = st[lm * SLD + 4 * s + kk];
                     }
@@ -151,7 +153,7 @@ gemm_nn_res_kernel(GemmNN g, int mblocks, int ntiles, int64_t total_tiles, int g
         // are still on their way back from LDS, so the LDS round trip hides behind the next
         // tile's writes instead of stalling every step.  (LDS operations of one wave complete in
         // issue order, so slot reuse two steps later needs no wait.)
-        float* scr = scratch + wave * 2 * 16 * GR_SCR_LD;
+        float* scr = scratch + wave * 2 * 16 * GR_SCR_LD;   // 8 waves x 2 slots
         auto put = [&](int i) {
             float* sl = scr + (i & 1) * 16 * GR_SCR_LD;
 #pragma unroll
@@ -194,12 +196,13 @@ gemm_nn_res_kernel(GemmNN g, int mblocks, int ntiles, int64_t total_tiles, int g
 
 // Eligibility and launch.  Returns RST_OK and sets *launched = true when the
 // resident kernel took the problem; otherwise leaves it to the generic kernel.
+// m-tiles (16 rows) per wave; a block covers 2*MT tiles.  Fewest blocks, then least padding.
 static int res_pick_mt(int M) {
-    static const int cand[] = {9, 8, 6, 3};
+    static const int cand[] = {5, 4, 3, 2};
     int best = 0;
     int64_t best_pad = INT64_MAX, best_blocks = INT64_MAX;
     for (int mt : cand) {
-        const int64_t blocks = cdiv(M, 16 * mt), pad = blocks * 16 * mt;
+        const int64_t blocks = cdiv(M, 32 * mt), pad = blocks * 32 * mt;
         if (blocks < best_blocks || (blocks == best_blocks && pad < best_pad)) { best = mt; best_pad = pad; best_blocks = blocks; }
     }
     return best;
@@ -207,29 +210,30 @@ static int res_pick_mt(int M) {
 
 int gemm_nn_res_try(const GemmNN& g, hipStream_t stream, bool* launched) {
     *launched = false;
+    if (getenv("RST_NORES")) return RST_OK;
     const bool al = aligned16(g.X) && aligned16(g.Y) && (g.R == nullptr || aligned16(g.R));
     const bool strides4 = (g.N % 4 == 0) && (g.ldx % 4 == 0) && (g.x_s1 % 4 == 0) && (g.x_s2 % 4 == 0) &&
                           (g.ldy % 4 == 0) && (g.y_s1 % 4 == 0) && (g.y_s2 % 4 == 0) &&
                           (g.R == nullptr || ((g.ldr % 4 == 0) && (g.r_s1 % 4 == 0) && (g.r_s2 % 4 == 0)));
-    if (!al || !strides4 || g.accumulate) return RST_OK;
+    // residual shapes are served at least as well by the general DMA kernel (more waves in flight)
+    if (!al || !strides4 || g.accumulate || g.R != nullptr) return RST_OK;
     // weight tiles are compiled for the channel counts of the dim=48 network's high-resolution levels
     if (g.K != 48 && g.K != 60 && g.K != 96 && g.K != 120) return RST_OK;
     const int64_t ntiles = cdiv(g.N, GR_BN);
     const int64_t total = ntiles * g.nb1 * g.nb2;
     if (total < 512 || ntiles > (1ll << 30)) return RST_OK;      // too little work to amortise resident weights
     const int mt = res_pick_mt(g.M);
-    const int mblocks = (int)cdiv(g.M, 16 * mt);
+    const int mblocks = (int)cdiv(g.M, 32 * mt);
     if (mblocks > 4) return RST_OK;
     const int ksm = g.K / 4;
 
     int dev = 0, cus = 256;
     RST_HIP(hipGetDevice(&dev));
     RST_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    if (g.R != nullptr && mt >= 8 && ksm >= 24) return RST_OK;     // would not fit the register file with the residual rows
-    const size_t lds = (size_t)(2 * 4 * ksm * GR_BN + 8 * 16 * GR_SCR_LD) * sizeof(float);
+    const size_t lds = (size_t)(2 * 4 * ksm * GR_BN + 16 * 16 * GR_SCR_LD) * sizeof(float);
     int per_cu = 1;
     int groups = 0;
-    dim3 blk(256);
+    dim3 blk(512);
 
     const double nb = (double)g.nb1 * g.nb2;
     ProfScope prof(stream, "gemm_nn", 2.0 * g.M * g.K * g.N * nb,
@@ -240,9 +244,9 @@ int gemm_nn_res_try(const GemmNN& g, hipStream_t stream, bool* launched) {
         if (lds > 64 * 1024)                                                                                  \
             RST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                  \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
-        RST_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds));                       \
+        RST_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 512, lds));                       \
         if (per_cu < 1) per_cu = 1;                                                                           \
-        if (per_cu > 2) per_cu = 2;                                                                           \
+        if (per_cu > 1) per_cu = 1;                                                                           \
         groups = cus * per_cu / mblocks;                                                                      \
         groups -= groups % 8;                                                                                 \
         if (groups > total) groups = (int)(total - total % 8);                                                \
@@ -257,10 +261,10 @@ int gemm_nn_res_try(const GemmNN& g, hipStream_t stream, bool* launched) {
         default: GR_LAUNCH(MTV, 30); break;         \
     }
     switch (mt) {
+        case 2: GR_KS(2); break;
         case 3: GR_KS(3); break;
-        case 6: GR_KS(6); break;
-        case 8: GR_KS(8); break;
-        case 9: GR_KS(9); break;
+        case 4: GR_KS(4); break;
+        case 5: GR_KS(5); break;
         default: return RST_OK;
     }
 #undef GR_KS
