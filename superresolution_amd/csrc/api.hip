@@ -97,7 +97,7 @@ static void attn_carve_ws(const rst_block_desc* d, bool have_saved, Carver& cv, 
     const int64_t N = (int64_t)d->H * d->W;
     const int c = d->C / d->heads;
     const int BH = d->B * d->heads;
-    b.plan = gemm_nt_plan(c, c, N, BH);
+    b.plan = gemm_nt_plan(c, c, N, BH, 16);     // the softmax kernel adds the Gram slabs itself
     b.gram_part = cv.floats(gemm_nt_partial_floats(b.plan, c, c, BH));
     b.sqq_part = cv.floats((size_t)BH * b.plan.splits * c);
     b.sqk_part = cv.floats((size_t)BH * b.plan.splits * c);

@@ -11,17 +11,218 @@
 // v_mfma_f32_16x16x4_f32) and writes one partial slab; a second pass adds the
 // slabs in a fixed order, so results are bitwise reproducible.
 //
-// A and Bm are read straight from their NCHW planes: 16 lanes x 16 B cover 64
-// consecutive pixels of one channel row.  In LDS a row keeps its pixels
-// contiguous; MFMA lane (i, kk) takes pixels 4*kk..4*kk+3 of row i with one
-// ds_read_b128 and feeds them to four consecutive k-steps (the k order inside
-// a 16-pixel group is permuted identically for both operands, which leaves the
-// sum unchanged).
+// A and Bm are read straight from their NCHW planes by LDS-DMA (no staging registers).
+// In LDS a row keeps its pixels in 16-byte chunks; MFMA lane (i, kk) takes pixels
+// 4*kk..4*kk+3 of row i with one ds_read_b128 and feeds them to four consecutive k-steps
+// (the k order inside a 16-pixel group is permuted identically for both operands, which
+// leaves the sum unchanged).  The squared row norms are accumulated from the same operand
+// registers.
 #include "kernels.hpp"
 
 namespace rst {
 
 
+typedef __attribute__((address_space(1))) const void* nt_gptr;
+typedef __attribute__((address_space(3))) void* nt_lptr;
+
+constexpr int NT_STAGES = 3;
+
+// T1,T2: 16-row tiles per wave along M1/M2.  WR x WC x WK = 4 waves: WR*WC waves tile
+// the output, WK waves split the pixels of a stage.  A stage holds SP = 32 pixels (64 when
+// WK = 4) of every A row and B row of the block tile ([rows][SP], A rows first), brought in
+// by LDS-DMA in 1-KiB pieces (256/SP rows each), PPW pieces per wave per stage, three
+// stages deep.  The 16-byte chunk g of a row is stored at chunk position
+// g ^ (row & (SP/4-1)): the permutation is applied to the per-lane SOURCE address (the LDS
+// image of a piece stays lane-linear), so the 16 rows an operand read touches spread over
+// the banks.
+template <int T1, int T2>
+__global__ void __launch_bounds__(256, 2)
+gemm_nt_kernel(GemmNT g, int WR, int WC, int rblocks, int cblocks, int SP, int PPW) {
+    extern __shared__ __attribute__((aligned(16))) float ring[];
+    const int WK = 4 / (WR * WC);
+    const int R1 = 16 * T1 * WR, R2 = 16 * T2 * WC;      // block tile
+    const int cmask = SP / 4 - 1;
+    const int rows_per_piece = 256 / SP;                  // 1 KiB / (SP * 4 B)
+    const int lane_shift = SP == 64 ? 4 : 3;              // lanes per row of a piece = SP/4
+    const int stage_floats = PPW * 4 * 256;               // PPW pieces x 4 waves x 256 floats
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int bid = blockIdx.x;
+    const int cb = bid % cblocks; bid /= cblocks;
+    const int rb = bid % rblocks; bid /= rblocks;
+    const int sp = bid % g.splits; bid /= g.splits;
+    const int batch = bid;
+    const int b1 = batch / g.nb2, b2 = batch % g.nb2;
+
+    const float* Ab = g.A + (int64_t)b1 * g.a_s1 + (int64_t)b2 * g.a_s2;
+    const float* Bb = g.Bm + (int64_t)b1 * g.b_s1 + (int64_t)b2 * g.b_s2;
+    const int64_t p_begin = (int64_t)sp * g.chunk;
+    const int64_t p_end = min(g.N, p_begin + g.chunk);    // multiple of 4
+    const int nstages = (int)((p_end - p_begin + SP - 1) / SP);
+
+    // this lane's share of the PPW pieces of a stage (fixed for the whole kernel):
+    // piece (wave + 4 j) covers image rows piece*rows_per_piece .. ; lane -> one 16-byte chunk of one row
+    const float* rowbase[8];
+    int gchunk[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int row = (wave + 4 * j) * rows_per_piece + (lane >> lane_shift);
+        if (row < R1) {
+            rowbase[j] = Ab + (int64_t)min(rb * R1 + row, g.M1 - 1) * g.lda;
+        } else {
+            rowbase[j] = Bb + (int64_t)min(cb * R2 + min(row - R1, R2 - 1), g.M2 - 1) * g.ldb;
+        }
+        gchunk[j] = 4 * ((lane & cmask) ^ (row & cmask));
+    }
+    auto issue = [&](int s) {
+        float* st = ring + (s % NT_STAGES) * stage_floats;
+        const int64_t p = p_begin + (int64_t)s * SP;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < PPW) {
+                int64_t px = p + gchunk[j];
+                if (px > p_end - 4) px = p_end - 4;      // clamped duplicate; masked in the MFMA loop
+                __builtin_amdgcn_global_load_lds((nt_gptr)(rowbase[j] + px), (nt_lptr)(st + (wave + 4 * j) * 256), 16, 0, 0);
+            }
+        }
+    };
+
+    f32x4 acc[T1][T2];
+    float sqa[T1], sqb[T2];
+#pragma unroll
+    for (int i = 0; i < T1; ++i) {
+        sqa[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < T2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < T2; ++j) sqb[j] = 0.f;
+
+    const int wk = wave % WK;
+    const int wt = wave / WK;
+    const int wr = wt / WC, wc = wt % WC;
+    const int li = lane & 15, kk = lane >> 4;
+    const int px_per_wave = SP / WK;                 // 32, 16 or 16
+
+    // prologue: two stages in flight (re-issuing the last stage keeps the per-wave count fixed)
+    issue(0);
+    issue(nstages > 1 ? 1 : 0);
+    for (int s = 0; s < nstages; ++s) {
+        // stage s landed for this wave (stage s+1 = PPW pieces may stay in flight), then for all;
+        // the barrier also frees the slot of stage s-1 for the refill
+        switch (PPW) {
+            case 1: asm volatile("s_waitcnt vmcnt(1)\n\ts_barrier" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)\n\ts_barrier" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)\n\ts_barrier" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory"); break;
+        }
+        issue(s + 2 < nstages ? s + 2 : nstages - 1);
+        const float* st = ring + (s % NT_STAGES) * stage_floats;
+        const int64_t p = p_begin + (int64_t)s * SP;
+        for (int q = 0; q < px_per_wave; q += 16) {
+            const int o = wk * px_per_wave + q + 4 * kk;       // this lane's 4 pixels inside the stage
+            const bool valid = p + o < p_end;
+            const int gch = o >> 2;
+            f32x4 av[T1], bv[T2];
+#pragma unroll
+            for (int i = 0; i < T1; ++i) {
+                const int row = wr * 16 * T1 + 16 * i + li;
+                av[i] = *reinterpret_cast<const f32x4*>(&st[row * SP + 4 * (gch ^ (row & cmask))]);
+                if (!valid) av[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                sqa[i] += av[i].x * av[i].x + av[i].y * av[i].y + av[i].z * av[i].z + av[i].w * av[i].w;
+            }
+#pragma unroll
+            for (int j = 0; j < T2; ++j) {
+                const int row = R1 + wc * 16 * T2 + 16 * j + li;
+                bv[j] = *reinterpret_cast<const f32x4*>(&st[row * SP + 4 * (gch ^ (row & cmask))]);
+                if (!valid) bv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                sqb[j] += bv[j].x * bv[j].x + bv[j].y * bv[j].y + bv[j].z * bv[j].z + bv[j].w * bv[j].w;
+            }
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int i = 0; i < T1; ++i)
+#pragma unroll
+                    for (int j = 0; j < T2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][s4], bv[j][s4], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // every DMA has landed and every wave has left the loop: the ring becomes reduction scratch
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    float* red = ring;        // [WK][WR*WC][T1*T2][64 lanes][4]
+    if (WK > 1) {
+#pragma unroll
+        for (int i = 0; i < T1; ++i)
+#pragma unroll
+            for (int j = 0; j < T2; ++j)
+                *reinterpret_cast<f32x4*>(&red[(((wk * (WR * WC) + wt) * (T1 * T2) + i * T2 + j) * 64 + lane) * 4]) = acc[i][j];
+        __syncthreads();
+    }
+    float* slab = g.partial + ((int64_t)batch * g.splits + sp) * (int64_t)g.M1 * g.M2;
+    if (wk == 0) {
+#pragma unroll
+        for (int i = 0; i < T1; ++i)
+#pragma unroll
+            for (int j = 0; j < T2; ++j) {
+                f32x4 v = acc[i][j];
+                for (int w = 1; w < WK; ++w) {
+                    const f32x4 o = *reinterpret_cast<const f32x4*>(&red[(((w * (WR * WC) + wt) * (T1 * T2) + i * T2 + j) * 64 + lane) * 4]);
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
+                const int col = cb * R2 + wc * 16 * T2 + 16 * j + li;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = rb * R1 + wr * 16 * T1 + 16 * i + 4 * kk + r;
+                    if (row < g.M1 && col < g.M2) slab[(int64_t)row * g.M2 + col] = v[r];
+                }
+            }
+    }
+    // ---- squared row norms: lane (li, kk) holds the part of row li over its pixels ----
+    if (g.sqA_partial != nullptr || g.sqB_partial != nullptr) {
+        __syncthreads();                              // the accumulator exchange above is done with `red`
+        float* sq = ring;                             // [4 waves][T1 + T2][16]
+#pragma unroll
+        for (int i = 0; i < T1; ++i) {
+            float v = sqa[i];
+            v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+            if (kk == 0) sq[(wave * (T1 + T2) + i) * 16 + li] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < T2; ++j) {
+            float v = sqb[j];
+            v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+            if (kk == 0) sq[(wave * (T1 + T2) + T1 + j) * 16 + li] = v;
+        }
+        __syncthreads();
+        // rows of A: tile (wr, i); summed over the WK pixel-split waves with wc == 0
+        if (g.sqA_partial != nullptr && cb == 0) {
+            for (int e = tid; e < R1; e += 256) {
+                const int twr = e / (16 * T1), ti = (e / 16) % T1, l = e % 16;
+                float v = 0.f;
+                for (int w = 0; w < WK; ++w) v += sq[(((twr * WC + 0) * WK + w) * (T1 + T2) + ti) * 16 + l];
+                const int row = rb * R1 + e;
+                if (row < g.M1) g.sqA_partial[((int64_t)batch * g.splits + sp) * g.M1 + row] = v;
+            }
+        }
+        if (g.sqB_partial != nullptr && rb == 0) {
+            for (int e = tid; e < R2; e += 256) {
+                const int twc = e / (16 * T2), tj = (e / 16) % T2, l = e % 16;
+                float v = 0.f;
+                for (int w = 0; w < WK; ++w) v += sq[(((0 * WC + twc) * WK + w) * (T1 + T2) + T1 + tj) * 16 + l];
+                const int row = cb * R2 + e;
+                if (row < g.M2) g.sqB_partial[((int64_t)batch * g.splits + sp) * g.M2 + row] = v;
+            }
+        }
+    }
+}
+
+// ---- fallback for operands that are not 16-byte aligned / pixel counts not multiples of 4:
+// register-staged loads with per-element bounds checks, same tiling and numerics ----
 constexpr int NT_KP = 64;          // pixels staged per iteration
 constexpr int NT_LD = NT_KP + 4;   // LDS row stride (floats): 17 x 16 B
 
@@ -29,7 +230,7 @@ constexpr int NT_LD = NT_KP + 4;   // LDS row stride (floats): 17 x 16 B
 // waves tile the output, WK waves split the staged pixels.
 template <int T1, int T2, bool VEC>
 __global__ void __launch_bounds__(256)
-gemm_nt_kernel(GemmNT g, int WR, int WC, int rblocks, int cblocks) {
+gemm_nt_generic_kernel(GemmNT g, int WR, int WC, int rblocks, int cblocks) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int WK = 4 / (WR * WC);
     const int R1 = 16 * T1 * WR, R2 = 16 * T2 * WC;     // block tile
@@ -227,7 +428,7 @@ static NtDim nt_pick_dim(int M, int maxW) {
 }
 
 
-NtPlan gemm_nt_plan(int M1, int M2, int64_t N, int nbatch) {
+NtPlan gemm_nt_plan(int M1, int M2, int64_t N, int nbatch, int max_splits_cap) {
     NtPlan p;
     p.d1 = nt_pick_dim(M1, 2);
     p.d2 = nt_pick_dim(M2, 2);
@@ -236,6 +437,7 @@ NtPlan gemm_nt_plan(int M1, int M2, int64_t N, int nbatch) {
     int64_t want = cdiv(1024, tiles);
     int64_t max_splits = cdiv(N, 512);
     if (want > max_splits) want = max_splits;
+    if (max_splits_cap > 0 && want > max_splits_cap) want = max_splits_cap;
     if (want < 1) want = 1;
     p.chunk = round_up(cdiv(N, want), 64);
     p.splits = (int)cdiv(N, p.chunk);
@@ -257,17 +459,39 @@ int gemm_nt_launch(GemmNT g, const NtPlan& p, hipStream_t stream) {
                      (g.b_s1 % 4 == 0) && (g.b_s2 % 4 == 0) && aligned16(g.A) && aligned16(g.Bm);
     const int R1 = 16 * p.d1.T * WR, R2 = 16 * p.d2.T * WC;
     const int WK = 4 / (WR * WC);
-    size_t lds = (size_t)(R1 + R2) * NT_LD * sizeof(float);
+    const int SP = WK == 4 ? 64 : 32;
+    const int rows_per_wave_piece = 4 * (256 / SP);                 // rows covered by one piece of each of the 4 waves
+    const int PPW = (int)cdiv(R1 + R2, rows_per_wave_piece);
+    RST_REQUIRE(PPW <= 8, "gemm_nt: tile too large");
+    size_t lds = (size_t)NT_STAGES * PPW * 4 * 256 * sizeof(float);
     const size_t red = (size_t)WK * WR * WC * p.d1.T * p.d2.T * 64 * 4 * sizeof(float);
     if (WK > 1 && red > lds) lds = red;
     dim3 gd((unsigned)grid), blk(256);
+    if (!vec) {
+        size_t glds = (size_t)(R1 + R2) * NT_LD * sizeof(float);
+        if (WK > 1 && red > glds) glds = red;
+        ProfScope prof(stream, "gemm_nt_splitk", 2.0 * g.M1 * g.M2 * g.N * g.nb1 * g.nb2,
+                       4.0 * g.nb1 * g.nb2 * ((double)(g.M1 + g.M2) * g.N + (double)p.splits * g.M1 * g.M2));
+#define NTG_CASE(a, b) \
+        if (p.d1.T == a && p.d2.T == b) hipLaunchKernelGGL((gemm_nt_generic_kernel<a, b, false>), gd, blk, glds, stream, g, WR, WC, p.d1.blocks, p.d2.blocks); else
+        NTG_CASE(1, 1) NTG_CASE(1, 2) NTG_CASE(1, 3) NTG_CASE(1, 4)
+        NTG_CASE(2, 1) NTG_CASE(2, 2) NTG_CASE(2, 3) NTG_CASE(2, 4)
+        NTG_CASE(3, 1) NTG_CASE(3, 2) NTG_CASE(3, 3) NTG_CASE(3, 4)
+        NTG_CASE(4, 1) NTG_CASE(4, 2) NTG_CASE(4, 3) NTG_CASE(4, 4)
+        { return fail(RST_ERR_INVALID, "gemm_nt: bad tile"); }
+#undef NTG_CASE
+        RST_LAUNCH_CHECK();
+        return RST_OK;
+    }
     const double nb = (double)g.nb1 * g.nb2;
     ProfScope prof(stream, "gemm_nt_splitk", 2.0 * g.M1 * g.M2 * g.N * nb,
                    4.0 * nb * ((double)(g.M1 + g.M2) * g.N + (double)p.splits * g.M1 * g.M2));
 #define NT_CASE(a, b)                                                                                         \
     if (p.d1.T == a && p.d2.T == b) {                                                                         \
-        if (vec) hipLaunchKernelGGL((gemm_nt_kernel<a, b, true>), gd, blk, lds, stream, g, WR, WC, p.d1.blocks, p.d2.blocks);  \
-        else     hipLaunchKernelGGL((gemm_nt_kernel<a, b, false>), gd, blk, lds, stream, g, WR, WC, p.d1.blocks, p.d2.blocks); \
+        if (lds > 64 * 1024)                                                                                  \
+            RST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<a, b>),                  \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
+        hipLaunchKernelGGL((gemm_nt_kernel<a, b>), gd, blk, lds, stream, g, WR, WC, p.d1.blocks, p.d2.blocks, SP, PPW); \
     } else
     NT_CASE(1, 1) NT_CASE(1, 2) NT_CASE(1, 3) NT_CASE(1, 4)
     NT_CASE(2, 1) NT_CASE(2, 2) NT_CASE(2, 3) NT_CASE(2, 4)

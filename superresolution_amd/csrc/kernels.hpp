@@ -39,7 +39,8 @@ struct GemmNT {
 };
 struct NtDim { int T, W, blocks; };
 struct NtPlan { NtDim d1, d2; int splits; int64_t chunk; };
-NtPlan gemm_nt_plan(int M1, int M2, int64_t N, int nbatch);
+// max_splits_cap > 0 bounds the number of pixel splits (the consumer adds the slabs serially)
+NtPlan gemm_nt_plan(int M1, int M2, int64_t N, int nbatch, int max_splits_cap = 0);
 size_t gemm_nt_partial_floats(const NtPlan& p, int M1, int M2, int nbatch);
 int gemm_nt_launch(GemmNT g, const NtPlan& p, hipStream_t stream);
 int reduce_slabs_launch(const float* partial, float* out, int64_t elems, int groups, int slabs_per_group,

@@ -80,6 +80,23 @@ def bench_ln():
         print(f"layernorm C={C} H={H} {us:8.1f} us {2 * 4.0 * x.numel() / us / 1e3:7.1f} GB/s")
 
 
+def bench_gram():
+    from superresolution_amd import ops as O
+    import ctypes
+    for label, C, heads, H in [("L1 c48", 48, 1, 256), ("D1 c96", 96, 1, 256), ("L2 c48x2", 96, 2, 128), ("L3 c48x4", 192, 4, 64), ("L4 c48x8", 384, 8, 32)]:
+        # time the whole attention forward minus its parts is awkward; time conv1x1 backward weight instead (same kernel)
+        x = torch.randn(B, C, H * H, device="cuda")
+        dy = torch.randn(B, 3 * C, H * H, device="cuda")
+        w = torch.randn(3 * C, C, device="cuda")
+        dw = torch.empty_like(w)
+        nb = lib.rst_conv1x1_bwd_workspace_bytes(B, C, 3 * C, H * H)
+        ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        us = timeit(lambda: lib.rst_conv1x1_bwd(x.data_ptr(), w.data_ptr(), dy.data_ptr(), None, 0, dw.data_ptr(), None, B, C, 3 * C, H * H, ws.data_ptr(), nb, S))
+        fl = 2.0 * 3 * C * C * H * H * B
+        by = 4.0 * 4 * C * H * H * B
+        print(f"wgrad {label} (3C x C) {us:8.1f} us {fl / us / 1e6:6.1f} TFLOP/s {by / us / 1e3:7.1f} GB/s")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("gemm", "all"):
@@ -88,3 +105,5 @@ if __name__ == "__main__":
         bench_dw()
     if what in ("ln", "all"):
         bench_ln()
+    if what in ("gram", "all"):
+        bench_gram()
