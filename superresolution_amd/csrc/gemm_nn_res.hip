@@ -210,7 +210,6 @@ static int res_pick_mt(int M) {
 
 int gemm_nn_res_try(const GemmNN& g, hipStream_t stream, bool* launched) {
     *launched = false;
-    if (getenv("RST_NORES")) return RST_OK;
     const bool al = aligned16(g.X) && aligned16(g.Y) && (g.R == nullptr || aligned16(g.R));
     const bool strides4 = (g.N % 4 == 0) && (g.ldx % 4 == 0) && (g.x_s1 % 4 == 0) && (g.x_s2 % 4 == 0) &&
                           (g.ldy % 4 == 0) && (g.y_s1 % 4 == 0) && (g.y_s2 % 4 == 0) &&

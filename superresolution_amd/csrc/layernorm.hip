@@ -16,11 +16,15 @@ template <int VEC> struct VecT;
 template <> struct VecT<1> { typedef float type; };
 template <> struct VecT<4> { typedef f32x4 type; };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int VEC>
 __device__ __forceinline__ void load_vec(float (&dst)[VEC], const float* p) {
     if constexpr (VEC == 4) {
         f32x4 v = *reinterpret_cast<const f32x4*>(p);
         dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    } else if constexpr (VEC == 2) {
+        f32x2 v = *reinterpret_cast<const f32x2*>(p);
+        dst[0] = v.x; dst[1] = v.y;
     } else {
         dst[0] = *p;
     }
@@ -30,6 +34,9 @@ __device__ __forceinline__ void store_vec(float* p, const float (&src)[VEC]) {
     if constexpr (VEC == 4) {
         f32x4 v = {src[0], src[1], src[2], src[3]};
         *reinterpret_cast<f32x4*>(p) = v;
+    } else if constexpr (VEC == 2) {
+        f32x2 v = {src[0], src[1]};
+        *reinterpret_cast<f32x2*>(p) = v;
     } else {
         *p = src[0];
     }
@@ -125,7 +132,7 @@ ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ weight, con
 // registers; one partial row per block goes to `partial` ([grid][2][C]) and a
 // second kernel adds the rows in a fixed order (deterministic).
 template <int VEC, int CPT>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__(1024)
 ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ weight, int with_bias,
               const float* __restrict__ dy, const float* addend, float* dx,
               float* __restrict__ partial, int C, int64_t N, int64_t tiles_per_sample, int64_t total_tiles) {
@@ -245,18 +252,31 @@ ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ weight, int
     }
 }
 
-// out[r][c] = sum_i partial[i][r][c]  (i over rows), fixed order.
-__global__ void ln_reduce_partials_kernel(const float* __restrict__ partial, int rows, int C,
-                                          float* __restrict__ dweight, float* __restrict__ dbias) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// out[r][c] = sum_i partial[i][r][c] (i over the partial rows), in a fixed order:
+// block = 64 channels x 16 row groups, each thread adds every 16th row, then the
+// 16 groups are added in order through LDS.
+__global__ void __launch_bounds__(1024)
+ln_reduce_partials_kernel(const float* __restrict__ partial, int rows, int C,
+                          float* __restrict__ dweight, float* __restrict__ dbias) {
+    __shared__ float red[2][16][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float a = 0.f, b = 0.f;
-    for (int i = 0; i < rows; ++i) {
-        a += partial[((int64_t)i * 2 + 0) * C + c];
-        b += partial[((int64_t)i * 2 + 1) * C + c];
+    if (c < C) {
+        for (int i = rg; i < rows; i += 16) {
+            a += partial[((int64_t)i * 2 + 0) * C + c];
+            b += partial[((int64_t)i * 2 + 1) * C + c];
+        }
     }
-    dweight[c] = a;
-    if (dbias != nullptr) dbias[c] = b;
+    red[0][rg][cl] = a;
+    red[1][rg][cl] = b;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+        float sa = 0.f, sb = 0.f;
+        for (int k = 0; k < 16; ++k) { sa += red[0][k][cl]; sb += red[1][k][cl]; }
+        dweight[c] = sa;
+        if (dbias != nullptr) dbias[c] = sb;
+    }
 }
 
 // ---- launch plan --------------------------------------------------------------
@@ -264,22 +284,36 @@ struct LnPlan {
     int vec, cpt, waves;
 };
 static bool ln_plan(int C, int64_t N, bool ptr_aligned, bool backward, LnPlan* p) {
-    // At most 8 waves (512 threads -> 256 registers per lane); the channel
-    // column of a pixel (and of dy in the backward) stays in registers.
-    int waves = (int)cdiv(C, 12);
-    if (waves > 8) waves = 8;
+    if (!backward) {
+        // forward: at most 8 waves (512 threads -> 256 registers per lane); the channel column of a
+        // pixel stays in registers
+        int waves = (int)cdiv(C, 12);
+        if (waves > 8) waves = 8;
+        const int cpt = (int)cdiv(C, waves);
+        if (cpt <= 12) p->cpt = 12;
+        else if (cpt <= 24) p->cpt = 24;
+        else if (cpt <= 48) p->cpt = 48;
+        else return false;
+        p->vec = (N % 4 == 0 && ptr_aligned && p->cpt <= 24) ? 4 : 1;
+        p->waves = waves;
+        return true;
+    }
+    // backward holds x and dy: up to 16 waves (1024 threads -> 128 registers per lane), so two
+    // blocks fit on a CU; the pixel vector shrinks as the channel share of a wave grows
+    int waves = (int)cdiv(C, 6);
+    if (waves > 16) waves = 16;
     const int cpt = (int)cdiv(C, waves);
-    if (cpt <= 12) p->cpt = 12;
-    else if (cpt <= 24) p->cpt = 24;
-    else if (cpt <= 48) p->cpt = 48;
+    int want_vec;
+    if (cpt <= 6) { p->cpt = 6; want_vec = 4; }
+    else if (cpt <= 12) { p->cpt = 12; want_vec = 2; }
+    else if (cpt <= 24) { p->cpt = 24; want_vec = 1; }
     else return false;
-    const int max_vec_cpt = backward ? 12 : 24;
-    p->vec = (N % 4 == 0 && ptr_aligned && p->cpt <= max_vec_cpt) ? 4 : 1;
+    p->vec = (ptr_aligned && N % want_vec == 0) ? want_vec : 1;
     p->waves = waves;
     return true;
 }
 
-static const int LN_BWD_MAX_BLOCKS = 1024;
+static const int LN_BWD_MAX_BLOCKS = 512;
 
 int layernorm_fwd_launch(const float* x, const float* weight, const float* bias, float* y,
                          int B, int C, int64_t N, hipStream_t stream) {
@@ -324,13 +358,14 @@ int layernorm_bwd_launch(const float* x, const float* weight, int with_bias, con
     float* partial = static_cast<float*>(ws);
     ProfScope prof(stream, "layernorm_bwd", 20.0 * B * C * N, (addend ? 4.0 : 3.0) * 4 * B * C * N);
 #define LN_BWD(V, CP) hipLaunchKernelGGL((ln_bwd_kernel<V, CP>), dim3(grid), blk, lds, stream, x, weight, with_bias, dy, addend, dx, partial, C, N, tps, total)
-    if (p.vec == 4 && p.cpt == 12) LN_BWD(4, 12);
+    if (p.vec == 4 && p.cpt == 6) LN_BWD(4, 6);
+    else if (p.vec == 2 && p.cpt == 12) LN_BWD(2, 12);
+    else if (p.vec == 1 && p.cpt == 6) LN_BWD(1, 6);
     else if (p.vec == 1 && p.cpt == 12) LN_BWD(1, 12);
-    else if (p.vec == 1 && p.cpt == 24) LN_BWD(1, 24);
-    else LN_BWD(1, 48);
+    else LN_BWD(1, 24);
 #undef LN_BWD
     RST_LAUNCH_CHECK();
-    hipLaunchKernelGGL(ln_reduce_partials_kernel, dim3((unsigned)cdiv(C, 128)), dim3(128), 0, stream,
+    hipLaunchKernelGGL(ln_reduce_partials_kernel, dim3((unsigned)cdiv(C, 64)), dim3(1024), 0, stream,
                        partial, grid, C, dweight, with_bias ? dbias : nullptr);
     RST_LAUNCH_CHECK();
     return RST_OK;

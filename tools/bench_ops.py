@@ -80,6 +80,17 @@ def bench_ln():
         print(f"layernorm C={C} H={H} {us:8.1f} us {2 * 4.0 * x.numel() / us / 1e3:7.1f} GB/s")
 
 
+def bench_lnbwd():
+    for Bq, C, H in [(8, 48, 128), (8, 96, 128), (8, 96, 64), (8, 192, 32), (8, 384, 16), (16, 96, 256)]:
+        x = torch.randn(Bq, C, H, H, device="cuda"); dy = torch.randn_like(x)
+        w = torch.randn(C, device="cuda")
+        dx = torch.empty_like(x); dw = torch.empty_like(w); db = torch.empty_like(w)
+        nb = lib.rst_layernorm_bwd_workspace_bytes(Bq, C, H * H)
+        ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        us = timeit(lambda: lib.rst_layernorm_bwd(x.data_ptr(), w.data_ptr(), 1, dy.data_ptr(), dx.data_ptr(), 0, dw.data_ptr(), db.data_ptr(), Bq, C, H * H, ws.data_ptr(), nb, S))
+        print(f"ln_bwd B={Bq} C={C} H={H} {us:8.1f} us {3 * 4.0 * x.numel() / us / 1e3:7.1f} GB/s")
+
+
 def bench_gram():
     from superresolution_amd import ops as O
     import ctypes
@@ -105,5 +116,7 @@ if __name__ == "__main__":
         bench_dw()
     if what in ("ln", "all"):
         bench_ln()
+    if what in ("lnbwd", "all"):
+        bench_lnbwd()
     if what in ("gram", "all"):
         bench_gram()
