@@ -56,6 +56,36 @@ static GemmNN conv1x1_args(const float* w, int Cout, int Cin, bool transposed, c
     return g;
 }
 
+// A channel LayerNorm that feeds a 1x1 convolution.  When the product kernels can fold it
+// (gemm_nn_ln_supported) the normalised tensor is never written: the weights are rescaled into
+// `fold` (Cout*Cin + 2*Cout floats) and the statistics are taken inside the product.  Otherwise
+// the input is normalised into `scratch` first.
+struct LnIn {
+    const float* gamma;
+    const float* beta;      // null: bias-free variant
+    float* scratch;         // B*C*N floats
+};
+static size_t ln_fold_floats(int Cout, int Cin) { return (size_t)Cout * Cin + 2 * (size_t)Cout; }
+
+// y = conv1x1(LN(x)) (+bias), through the folded path when possible
+static int ln_conv1x1(const LnIn& ln, const float* w, const float* bias, int Cout, int Cin, const float* x, float* y,
+                      int B, int64_t N, float* fold, hipStream_t stream) {
+    GemmNN g = conv1x1_args(w, Cout, Cin, false, x, y, B, N);
+    GemmNN probe = g;
+    probe.A = fold;
+    if (gemm_nn_ln_supported(probe)) {
+        float* s = fold + (size_t)Cout * Cin;
+        float* c = s + Cout;
+        RST_TRY(ln_fold_weights_launch(w, ln.gamma, ln.beta, bias, Cout, Cin, fold, s, c, stream));
+        g.A = fold; g.ln_mode = ln.beta ? 1 : 2; g.ln_s = s; g.ln_c = c;
+        return gemm_nn_launch(g, stream);
+    }
+    RST_TRY(layernorm_fwd_launch(x, ln.gamma, ln.beta, ln.scratch, B, Cin, N, stream));
+    g.X = ln.scratch;
+    g.bias = bias;
+    return gemm_nn_launch(g, stream);
+}
+
 // dW[M1][M2] = sum_b A[b] Bm[b]^T through split-K partials in `ws`
 static size_t wgrad_ws_floats(int M1, int M2, int64_t N, int B) {
     const NtPlan p = gemm_nt_plan(M1, M2, N, B);
@@ -78,7 +108,7 @@ struct AttnBufs {
     // kept for the backward pass (in `saved`) or scratch (in the workspace)
     float *t, *qkv, *attn, *ghat, *nq, *nk, *mfold;
     // scratch
-    float *gram_part, *sqq_part, *sqk_part;
+    float *gram_part, *sqq_part, *sqk_part, *fold;
     NtPlan plan;
 };
 
@@ -101,6 +131,7 @@ static void attn_carve_ws(const rst_block_desc* d, bool have_saved, Carver& cv, 
     b.gram_part = cv.floats(gemm_nt_partial_floats(b.plan, c, c, BH));
     b.sqq_part = cv.floats((size_t)BH * b.plan.splits * c);
     b.sqk_part = cv.floats((size_t)BH * b.plan.splits * c);
+    b.fold = cv.floats(ln_fold_floats(3 * d->C, d->C));
     if (!have_saved) {
         b.t = cv.floats((size_t)d->B * 3 * d->C * N);
         b.qkv = cv.floats((size_t)d->B * 3 * d->C * N);
@@ -121,8 +152,9 @@ static size_t attention_saved_bytes(const rst_block_desc* d) {
     return cv.total();
 }
 
+// `ln` (optional): x is the un-normalised input and the LayerNorm in front of the qkv convolution is applied here
 static int attention_fwd(const rst_block_desc* d, const rst_block_params* p, const float* x, const float* residual,
-                         float* y, void* saved, void* ws, size_t ws_bytes, hipStream_t stream) {
+                         float* y, void* saved, void* ws, size_t ws_bytes, hipStream_t stream, const LnIn* ln = nullptr) {
     RST_REQUIRE(x && y && p, "attention_fwd: null operand");
     RST_REQUIRE(p->temperature && p->qkv_weight && p->qkv_dw_weight && p->proj_weight, "attention_fwd: null parameter");
     RST_REQUIRE(!d->conv_bias || (p->qkv_bias && p->qkv_dw_bias && p->proj_bias), "attention_fwd: conv_bias set but a bias is null");
@@ -136,9 +168,13 @@ static int attention_fwd(const rst_block_desc* d, const rst_block_params* p, con
     attn_carve_ws(d, saved != nullptr, cw, b);
 
     // t = W_qkv x (+bias);  qkv = dw3x3(t)
-    GemmNN g1 = conv1x1_args(p->qkv_weight, 3 * C, C, false, x, b.t, B, N);
-    g1.bias = d->conv_bias ? p->qkv_bias : nullptr;
-    RST_TRY(gemm_nn_launch(g1, stream));
+    if (ln) {
+        RST_TRY(ln_conv1x1(*ln, p->qkv_weight, d->conv_bias ? p->qkv_bias : nullptr, 3 * C, C, x, b.t, B, N, b.fold, stream));
+    } else {
+        GemmNN g1 = conv1x1_args(p->qkv_weight, 3 * C, C, false, x, b.t, B, N);
+        g1.bias = d->conv_bias ? p->qkv_bias : nullptr;
+        RST_TRY(gemm_nn_launch(g1, stream));
+    }
     DwArgs dw{};
     dw.x = b.t; dw.x_bstride = (int64_t)3 * C * N; dw.w = p->qkv_dw_weight;
     dw.bias = d->conv_bias ? p->qkv_dw_bias : nullptr;
@@ -292,6 +328,7 @@ static void ffn_carve(const rst_block_desc* d, bool with_d, Carver& cv, FfnBufs&
 static size_t ffn_ws_bytes(const rst_block_desc* d) {
     Carver cv(nullptr); FfnBufs b{};
     ffn_carve(d, false, cv, b);
+    cv.floats(ln_fold_floats(2 * d->hidden, d->C));
     return cv.total();
 }
 static size_t ffn_saved_bytes(const rst_block_desc* d) {
@@ -300,24 +337,32 @@ static size_t ffn_saved_bytes(const rst_block_desc* d) {
     return cv.total();
 }
 
+// `ln` (optional, only without `saved`): as in attention_fwd, for the LayerNorm in front of project_in
 static int ffn_fwd(const rst_block_desc* d, const rst_block_params* p, const float* x, const float* residual, float* y,
-                   void* saved, void* ws, size_t ws_bytes, hipStream_t stream) {
+                   void* saved, void* ws, size_t ws_bytes, hipStream_t stream, const LnIn* ln = nullptr) {
     RST_REQUIRE(x && y && p, "ffn_fwd: null operand");
     RST_REQUIRE(p->pin_weight && p->ffn_dw_weight && p->pout_weight, "ffn_fwd: null parameter");
     RST_REQUIRE(!d->conv_bias || (p->pin_bias && p->ffn_dw_bias && p->pout_bias), "ffn_fwd: conv_bias set but a bias is null");
     FfnBufs b{};
+    float* fold = nullptr;
     if (saved) {
+        RST_REQUIRE(ln == nullptr, "ffn_fwd: the folded LayerNorm keeps nothing for a backward pass");
         Carver cs(saved); ffn_carve(d, true, cs, b);
     } else {
         if (ws == nullptr || ws_bytes < ffn_ws_bytes(d))
             return fail(RST_ERR_WORKSPACE, "ffn_fwd: workspace %zu < %zu bytes", ws_bytes, ffn_ws_bytes(d));
         Carver cw(ws); ffn_carve(d, false, cw, b);
+        fold = cw.floats(ln_fold_floats(2 * d->hidden, d->C));
     }
     const int B = d->B, C = d->C, Hd = d->hidden;
     const int64_t N = (int64_t)d->H * d->W;
-    GemmNN g1 = conv1x1_args(p->pin_weight, 2 * Hd, C, false, x, b.u, B, N);
-    g1.bias = d->conv_bias ? p->pin_bias : nullptr;
-    RST_TRY(gemm_nn_launch(g1, stream));
+    if (ln) {
+        RST_TRY(ln_conv1x1(*ln, p->pin_weight, d->conv_bias ? p->pin_bias : nullptr, 2 * Hd, C, x, b.u, B, N, fold, stream));
+    } else {
+        GemmNN g1 = conv1x1_args(p->pin_weight, 2 * Hd, C, false, x, b.u, B, N);
+        g1.bias = d->conv_bias ? p->pin_bias : nullptr;
+        RST_TRY(gemm_nn_launch(g1, stream));
+    }
     GateArgs ga{};
     ga.u = b.u; ga.u_bstride = (int64_t)2 * Hd * N; ga.w = p->ffn_dw_weight; ga.bias = d->conv_bias ? p->ffn_dw_bias : nullptr;
     ga.gout = b.g; ga.g_bstride = (int64_t)Hd * N; ga.d = b.d; ga.d_bstride = (int64_t)2 * Hd * N;
@@ -425,6 +470,13 @@ static int block_fwd(const rst_block_desc* d, const rst_block_params* p, const f
     if (saved) {
         Carver cs(saved); block_carve_saved(d, cs, s);
         xn1 = s.xn1; xn2 = s.xn2; x1 = s.x1;
+    }
+    if (!saved) {
+        // inference: the normalised tensors are consumed by one product each and never stored
+        const LnIn ln1{p->norm1_weight, d->ln_with_bias ? p->norm1_bias : nullptr, xn};
+        const LnIn ln2{p->norm2_weight, d->ln_with_bias ? p->norm2_bias : nullptr, xn};
+        RST_TRY(attention_fwd(d, p, x, x, x1, nullptr, sub, sub_bytes, stream, &ln1));
+        return ffn_fwd(d, p, x1, x1, y, nullptr, sub, sub_bytes, stream, &ln2);
     }
     RST_TRY(layernorm_fwd_launch(x, p->norm1_weight, d->ln_with_bias ? p->norm1_bias : nullptr, xn1, B, C, N, stream));
     RST_TRY(attention_fwd(d, p, xn1, x, x1, s.attn, sub, sub_bytes, stream));

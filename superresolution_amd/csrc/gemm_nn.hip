@@ -181,6 +181,37 @@ static int pick_mt(int M) {
 int gemm_nn_res_try(const GemmNN& g, hipStream_t stream, bool* launched);
 int gemm_nn_dma_try(const GemmNN& g, hipStream_t stream, bool* launched);
 
+// one wave per weight row
+__global__ void __launch_bounds__(64)
+ln_fold_weights_kernel(const float* __restrict__ w, const float* __restrict__ gamma, const float* __restrict__ beta,
+                       const float* __restrict__ bias, int K, float* __restrict__ folded, float* __restrict__ s,
+                       float* __restrict__ c) {
+    const int m = blockIdx.x, lane = threadIdx.x;
+    float ss = 0.f, cc = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float wv = w[(int64_t)m * K + k];
+        const float f = wv * gamma[k];
+        folded[(int64_t)m * K + k] = f;
+        ss += f;
+        if (beta != nullptr) cc = fmaf(wv, beta[k], cc);
+    }
+    ss = wave_sum(ss);
+    cc = wave_sum(cc);
+    if (lane == 0) {
+        s[m] = ss;
+        c[m] = cc + (bias != nullptr ? bias[m] : 0.f);
+    }
+}
+
+int ln_fold_weights_launch(const float* w, const float* gamma, const float* beta, const float* bias, int M, int K,
+                           float* folded, float* s, float* c, hipStream_t stream) {
+    RST_REQUIRE(w && gamma && folded && s && c && M > 0 && K > 0, "ln_fold_weights: bad operand");
+    ProfScope prof(stream, "ln_fold", 2.0 * M * K, 8.0 * M * K);
+    hipLaunchKernelGGL(ln_fold_weights_kernel, dim3((unsigned)M), dim3(64), 0, stream, w, gamma, beta, bias, K, folded, s, c);
+    RST_LAUNCH_CHECK();
+    return RST_OK;
+}
+
 int gemm_nn_launch(const GemmNN& g, hipStream_t stream) {
     RST_REQUIRE(g.M > 0 && g.K > 0 && g.N > 0 && g.nb1 > 0 && g.nb2 > 0,
                 "gemm_nn: empty problem (M=%d K=%d N=%lld batch=%dx%d)", g.M, g.K, (long long)g.N, g.nb1, g.nb2);
@@ -193,6 +224,7 @@ int gemm_nn_launch(const GemmNN& g, hipStream_t stream) {
         RST_TRY(gemm_nn_dma_try(g, stream, &done));
         if (done) return RST_OK;
     }
+    RST_REQUIRE(g.ln_mode == 0, "gemm_nn: folded LayerNorm on an unsupported shape");
     const int mt = pick_mt(g.M);
     const int mblocks = (int)cdiv(g.M, 16 * mt);
     const int64_t ntiles = cdiv(g.N, GN_BN);

@@ -26,8 +26,9 @@ constexpr int GD_SCR_LD = 36;
 
 typedef __attribute__((address_space(1))) const void* gd_gptr;
 typedef __attribute__((address_space(3))) void* gd_lptr;
+typedef float gd_f32x2 __attribute__((ext_vector_type(2)));
 
-template <int MTW, bool TRANSA, bool RES>
+template <int MTW, bool TRANSA, bool RES, bool LN>
 __global__ void __launch_bounds__(512, 4)
 gemm_nn_dma_kernel(GemmNN g, int mblocks) {
     constexpr int BM = 32 * MTW;
@@ -90,6 +91,24 @@ gemm_nn_dma_kernel(GemmNN g, int mblocks) {
         acc[i][1] = b4;
     }
 
+    // folded LayerNorm: sum and sum of squares over the channels of this wave's two pixel columns
+    gd_f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+
+    // per-row constants of the folded LayerNorm, fetched now and used in the epilogue
+    constexpr int LNN = LN ? MTW : 1;
+    f32x4 lns[LNN], lnc[LNN];
+    if constexpr (LN) {
+#pragma unroll
+        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + mh * 16 * MTW + 16 * i + 4 * kk + r;
+                const int mc = m < g.M ? m : g.M - 1;
+                lns[i][r] = g.ln_s[mc];
+                lnc[i][r] = g.ln_c[mc];
+            }
+    }
+
     // prologue: two chunks in flight (re-issuing the last chunk keeps the per-wave count fixed)
     issue(0);
     issue(nchunks > 1 ? 1 : 0);
@@ -124,6 +143,14 @@ gemm_nn_dma_kernel(GemmNN g, int mblocks) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) { bv[s][0] = 0.f; bv[s][1] = 0.f; }
         }
+        if constexpr (LN) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {      // rows past K were zeroed above
+                const gd_f32x2 xv = {bv[s][0], bv[s][1]};
+                s1 += xv;
+                s2 = __builtin_elementwise_fma(xv, xv, s2);
+            }
+        }
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -143,13 +170,32 @@ gemm_nn_dma_kernel(GemmNN g, int mblocks) {
     const int rr = lane >> 3, c4 = (lane & 7) * 4;
     const int64_t n = n0 + nq * 32 + c4;
     const bool nok = n < g.N;
+    float rstd[2] = {1.f, 1.f}, tco[2] = {0.f, 0.f};
+    if constexpr (LN) {
+        const float invk = 1.0f / (float)g.K;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float a = s1[j], q = s2[j];
+            a += __shfl_xor(a, 16); q += __shfl_xor(q, 16);
+            a += __shfl_xor(a, 32); q += __shfl_xor(q, 32);
+            const float mu = a * invk;
+            const float var = fmaxf(q * invk - mu * mu, 0.f);
+            rstd[j] = 1.0f / sqrtf(var + 1e-5f);
+            tco[j] = g.ln_mode == 1 ? -mu : 0.f;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MTW; ++i) {
         float* sl = scr + (i & 1) * 16 * GD_SCR_LD;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            sl[(4 * kk + r) * GD_SCR_LD + lm] = acc[i][0][r];
-            sl[(4 * kk + r) * GD_SCR_LD + 16 + lm] = acc[i][1][r];
+            float v0 = acc[i][0][r], v1 = acc[i][1][r];
+            if constexpr (LN) {
+                v0 = fmaf(rstd[0], fmaf(tco[0], lns[i][r], v0), lnc[i][r]);
+                v1 = fmaf(rstd[1], fmaf(tco[1], lns[i][r], v1), lnc[i][r]);
+            }
+            sl[(4 * kk + r) * GD_SCR_LD + lm] = v0;
+            sl[(4 * kk + r) * GD_SCR_LD + 16 + lm] = v1;
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -188,16 +234,27 @@ static int dma_pick_mtw(int M, int K) {
     return best;
 }
 
-int gemm_nn_dma_try(const GemmNN& g, hipStream_t stream, bool* launched) {
-    *launched = false;
+static bool dma_shape_ok(const GemmNN& g) {
     const bool al = aligned16(g.X) && aligned16(g.Y) && aligned16(g.A) && (g.R == nullptr || aligned16(g.R));
     const bool strides4 = (g.N % 4 == 0) && (g.ldx % 4 == 0) && (g.x_s1 % 4 == 0) && (g.x_s2 % 4 == 0) &&
                           (g.ldy % 4 == 0) && (g.y_s1 % 4 == 0) && (g.y_s2 % 4 == 0) &&
                           (g.lda % 4 == 0) && (g.a_s1 % 4 == 0) && (g.a_s2 % 4 == 0) &&
                           (g.R == nullptr || ((g.ldr % 4 == 0) && (g.r_s1 % 4 == 0) && (g.r_s2 % 4 == 0)));
-    if (!al || !strides4 || g.K % 4 != 0 || g.K < 4) return RST_OK;
-    if (g.transA && (g.M % 4 != 0 || g.M < 4)) return RST_OK;
-    if ((int64_t)g.nb1 * g.nb2 > 65535) return RST_OK;
+    if (!al || !strides4 || g.K % 4 != 0 || g.K < 4) return false;
+    if (g.transA && (g.M % 4 != 0 || g.M < 4)) return false;
+    if ((int64_t)g.nb1 * g.nb2 > 65535) return false;
+    return true;
+}
+
+bool gemm_nn_ln_supported(const GemmNN& g) {
+    return dma_shape_ok(g) && !g.transA && g.R == nullptr && !g.accumulate && g.bias == nullptr &&
+           g.a_s1 == 0 && g.a_s2 == 0;
+}
+
+int gemm_nn_dma_try(const GemmNN& g, hipStream_t stream, bool* launched) {
+    *launched = false;
+    if (!dma_shape_ok(g)) return RST_OK;
+    if (g.ln_mode != 0 && !gemm_nn_ln_supported(g)) return fail(RST_ERR_INVALID, "gemm_nn: folded LayerNorm on an unsupported shape");
     const int mtw = dma_pick_mtw(g.M, g.K);
     const int mblocks = (int)cdiv(g.M, 32 * mtw);
     const int64_t ntiles = cdiv(g.N, GD_BN);
@@ -205,12 +262,13 @@ int gemm_nn_dma_try(const GemmNN& g, hipStream_t stream, bool* launched) {
     if (gx >= (1ll << 31)) return RST_OK;
     dim3 grid((unsigned)gx, (unsigned)(g.nb1 * g.nb2)), blk(512);
     const double nb = (double)g.nb1 * g.nb2;
-    ProfScope prof(stream, "gemm_nn", 2.0 * g.M * g.K * g.N * nb,
+    ProfScope prof(stream, g.ln_mode ? "gemm_nn_ln" : "gemm_nn", 2.0 * g.M * g.K * g.N * nb,
                    4.0 * nb * g.N * (g.K + g.M * (1.0 + (g.R ? 1.0 : 0.0) + (g.accumulate ? 1.0 : 0.0))));
-#define GD_LAUNCH(MT, TA, RS) hipLaunchKernelGGL((gemm_nn_dma_kernel<MT, TA, RS>), grid, blk, 0, stream, g, mblocks)
+#define GD_LAUNCH(MT, TA, RS) hipLaunchKernelGGL((gemm_nn_dma_kernel<MT, TA, RS, false>), grid, blk, 0, stream, g, mblocks)
 #define GD_CASE(MT)                                                        \
     case MT:                                                               \
-        if (g.transA) { if (g.R) GD_LAUNCH(MT, true, true); else GD_LAUNCH(MT, true, false); }   \
+        if (g.ln_mode != 0) hipLaunchKernelGGL((gemm_nn_dma_kernel<MT, false, false, true>), grid, blk, 0, stream, g, mblocks); \
+        else if (g.transA) { if (g.R) GD_LAUNCH(MT, true, true); else GD_LAUNCH(MT, true, false); }   \
         else          { if (g.R) GD_LAUNCH(MT, false, true); else GD_LAUNCH(MT, false, false); } \
         break;
     switch (mtw) {

@@ -25,8 +25,9 @@ constexpr int GR_SCR_LD = 36;                 // per-wave transpose scratch row 
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int MT, int KS, bool RES>
+template <int MT, int KS, bool RES, bool LN>
 __global__ void __launch_bounds__(512, 2)
 gemm_nn_res_kernel(GemmNN g, int mblocks, int ntiles, int64_t total_tiles, int groups) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -64,6 +65,18 @@ gemm_nn_res_kernel(GemmNN g, int mblocks, int ntiles, int64_t total_tiles, int g
     float wreg[MT][KS];
     int64_t cur_b = -1;
     f32x4 acc[MT][2];
+    // folded LayerNorm: per-row constants of the block's rows, kept in LDS behind the scratch
+    float* lnS = scratch + 16 * 16 * GR_SCR_LD;      // [32*MT] row sums, then [32*MT] row constants
+    float* lnC = lnS + 32 * MT;
+    if constexpr (LN) {
+        for (int e = tid; e < 32 * MT; e += 512) {
+            const int m = mb * 32 * MT + e;
+            const int mc = m < g.M ? m : g.M - 1;
+            lnS[e] = g.ln_s[mc];
+            lnC[e] = g.ln_c[mc];
+        }
+        __syncthreads();
+    }
 
     if (t_begin < t_end) issue_tile(t_begin, 0);
     int buf = 0;
@@ -136,10 +149,18 @@ gemm_nn_res_kernel(GemmNN g, int mblocks, int ntiles, int64_t total_tiles, int g
             acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         const float* Xs = smem + buf * BUF + wn0 + lm;
+        // LayerNorm statistics of this wave's two pixel columns (sum and sum of squares over the
+        // channels, two columns per packed instruction) ride along with the product
+        f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             const float x0 = Xs[(4 * s + kk) * GR_BN];
             const float x1 = Xs[(4 * s + kk) * GR_BN + 16];
+            if constexpr (LN) {
+                const f32x2 xv = {x0, x1};
+                s1 += xv;
+                s2 = __builtin_elementwise_fma(xv, xv, s2);
+            }
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[i][s], x0, acc[i][0], 0, 0, 0);
@@ -154,12 +175,35 @@ gemm_nn_res_kernel(GemmNN g, int mblocks, int ntiles, int64_t total_tiles, int g
         // tile's writes instead of stalling every step.  (LDS operations of one wave complete in
         // issue order, so slot reuse two steps later needs no wait.)
         float* scr = scratch + wave * 2 * 16 * GR_SCR_LD;   // 8 waves x 2 slots
+        float rstd[2] = {1.f, 1.f}, tco[2] = {0.f, 0.f};
+        if constexpr (LN) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float a = s1[j], q = s2[j];
+                a += __shfl_xor(a, 16); q += __shfl_xor(q, 16);
+                a += __shfl_xor(a, 32); q += __shfl_xor(q, 32);
+                const float mu = a * (1.0f / KROWS);
+                const float var = fmaxf(q * (1.0f / KROWS) - mu * mu, 0.f);
+                rstd[j] = 1.0f / sqrtf(var + 1e-5f);
+                tco[j] = g.ln_mode == 1 ? -mu : 0.f;
+            }
+        }
         auto put = [&](int i) {
             float* sl = scr + (i & 1) * 16 * GR_SCR_LD;
+            f32x4 ls = {0.f, 0.f, 0.f, 0.f}, lc = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (LN) {
+                ls = *reinterpret_cast<const f32x4*>(&lnS[mg * 16 * MT + 16 * i + 4 * kk]);
+                lc = *reinterpret_cast<const f32x4*>(&lnC[mg * 16 * MT + 16 * i + 4 * kk]);
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                sl[(4 * kk + r) * GR_SCR_LD + lm] = acc[i][0][r];
-                sl[(4 * kk + r) * GR_SCR_LD + 16 + lm] = acc[i][1][r];
+                float v0 = acc[i][0][r], v1 = acc[i][1][r];
+                if constexpr (LN) {
+                    v0 = fmaf(rstd[0], fmaf(tco[0], ls[r], v0), lc[r]);
+                    v1 = fmaf(rstd[1], fmaf(tco[1], ls[r], v1), lc[r]);
+                }
+                sl[(4 * kk + r) * GR_SCR_LD + lm] = v0;
+                sl[(4 * kk + r) * GR_SCR_LD + 16 + lm] = v1;
             }
         };
         f32x4 pend[2];
@@ -197,11 +241,12 @@ gemm_nn_res_kernel(GemmNN g, int mblocks, int ntiles, int64_t total_tiles, int g
 // Eligibility and launch.  Returns RST_OK and sets *launched = true when the
 // resident kernel took the problem; otherwise leaves it to the generic kernel.
 // m-tiles (16 rows) per wave; a block covers 2*MT tiles.  Fewest blocks, then least padding.
-static int res_pick_mt(int M) {
+static int res_pick_mt(int M, int max_mt) {
     static const int cand[] = {5, 4, 3, 2};
     int best = 0;
     int64_t best_pad = INT64_MAX, best_blocks = INT64_MAX;
     for (int mt : cand) {
+        if (mt > max_mt) continue;
         const int64_t blocks = cdiv(M, 32 * mt), pad = blocks * 32 * mt;
         if (blocks < best_blocks || (blocks == best_blocks && pad < best_pad)) { best = mt; best_pad = pad; best_blocks = blocks; }
     }
@@ -216,12 +261,14 @@ int gemm_nn_res_try(const GemmNN& g, hipStream_t stream, bool* launched) {
                           (g.R == nullptr || ((g.ldr % 4 == 0) && (g.r_s1 % 4 == 0) && (g.r_s2 % 4 == 0)));
     // residual shapes are served at least as well by the general DMA kernel (more waves in flight)
     if (!al || !strides4 || g.accumulate || g.R != nullptr) return RST_OK;
+    if (g.ln_mode != 0 && g.K != 48 && g.K != 96) return RST_OK;    // folded LayerNorm: compiled for the two widths it meets here
     // weight tiles are compiled for the channel counts of the dim=48 network's high-resolution levels
     if (g.K != 48 && g.K != 60 && g.K != 96 && g.K != 120) return RST_OK;
     const int64_t ntiles = cdiv(g.N, GR_BN);
     const int64_t total = ntiles * g.nb1 * g.nb2;
     if (total < 512 || ntiles > (1ll << 30)) return RST_OK;      // too little work to amortise resident weights
-    const int mt = res_pick_mt(g.M);
+    // five row tiles of 96-deep weights plus the LayerNorm statistics do not fit the register file
+    const int mt = res_pick_mt(g.M, (g.ln_mode != 0 && g.K > 48) ? 4 : 5);
     const int mblocks = (int)cdiv(g.M, 32 * mt);
     if (mblocks > 4) return RST_OK;
     const int ksm = g.K / 4;
@@ -229,17 +276,18 @@ int gemm_nn_res_try(const GemmNN& g, hipStream_t stream, bool* launched) {
     int dev = 0, cus = 256;
     RST_HIP(hipGetDevice(&dev));
     RST_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const size_t lds = (size_t)(2 * 4 * ksm * GR_BN + 16 * 16 * GR_SCR_LD) * sizeof(float);
+    const size_t lds = (size_t)(2 * 4 * ksm * GR_BN + 16 * 16 * GR_SCR_LD + 2 * 32 * mt) * sizeof(float);
     int per_cu = 1;
     int groups = 0;
     dim3 blk(512);
 
     const double nb = (double)g.nb1 * g.nb2;
-    ProfScope prof(stream, "gemm_nn", 2.0 * g.M * g.K * g.N * nb,
+    ProfScope prof(stream, g.ln_mode ? "gemm_nn_ln" : "gemm_nn", 2.0 * g.M * g.K * g.N * nb,
                    4.0 * nb * g.N * (g.K + g.M * (1.0 + (g.R ? 1.0 : 0.0) + (g.accumulate ? 1.0 : 0.0))));
 #define GR_LAUNCH(MTV, KSV)                                                                                   \
     do {                                                                                                      \
-        auto kern = g.R ? gemm_nn_res_kernel<MTV, KSV, true> : gemm_nn_res_kernel<MTV, KSV, false>;          \
+        auto kern = gemm_nn_res_kernel<MTV, KSV, false, false>;                                               \
+        if constexpr (KSV == 12 || KSV == 24) { if (g.ln_mode != 0) kern = gemm_nn_res_kernel<MTV, KSV, false, true>; } \
         if (lds > 64 * 1024)                                                                                  \
             RST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                  \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \

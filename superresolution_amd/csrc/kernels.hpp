@@ -23,8 +23,23 @@ struct GemmNN {
     const float* bias;
     int M, K; int64_t N; int nb1, nb2;
     int accumulate;
+    // Channel LayerNorm of X folded into the product (ln_mode != 0): A holds W o gamma (columns
+    // scaled), ln_s[m] = sum_k A[m][k], ln_c[m] = sum_k W[m][k] beta[k] (+ conv bias), and the
+    // kernel takes mean / variance over the K rows of every X column while it multiplies:
+    //   mode 1 (with mean):  Y = rstd * (A X - mean * ln_s) + ln_c
+    //   mode 2 (bias-free):  Y = rstd * (A X) + ln_c          (variance still about the mean)
+    int ln_mode;
+    const float* ln_s;
+    const float* ln_c;
 };
 int gemm_nn_launch(const GemmNN& g, hipStream_t stream);
+// true when a product with ln_mode set can be served (the fused kernels need 16-byte aligned
+// operands); otherwise the caller normalises first and multiplies plainly
+bool gemm_nn_ln_supported(const GemmNN& g);
+// folded[m][k] = w[m][k] * gamma[k];  s[m] = sum_k folded[m][k];  c[m] = sum_k w[m][k] * beta[k] + bias[m]
+// (beta, bias may be null)
+int ln_fold_weights_launch(const float* w, const float* gamma, const float* beta, const float* bias, int M, int K,
+                           float* folded, float* s, float* c, hipStream_t stream);
 
 // ---- gemm_nt.hip ----
 struct GemmNT {

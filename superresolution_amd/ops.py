@@ -240,13 +240,15 @@ NORM_FIELDS = ("norm1_weight", "norm1_bias", "norm2_weight", "norm2_bias")
 def _composite(kind: str, fields: Sequence[str]):
     """Build an autograd Function for one of the composite C entry points.
 
-    forward(x, heads, hidden, ln_with_bias, conv_bias, *params) where params
-    follow `fields` (None for absent biases)."""
+    forward(x, heads, hidden, ln_with_bias, conv_bias, keep, *params) where
+    params follow `fields` (None for absent biases) and `keep` says whether a
+    backward pass can follow (see _keep): only then is the saved buffer
+    allocated and filled."""
     fwd_name, bwd_name = f"rst_{kind}_fwd", f"rst_{kind}_bwd"
 
     class Fn(torch.autograd.Function):
         @staticmethod
-        def forward(ctx, x, heads, hidden, ln_with_bias, conv_bias, *params):
+        def forward(ctx, x, heads, hidden, ln_with_bias, conv_bias, keep, *params):
             lib = _lib.load()
             x = _require(x, f"{kind} x")
             B, C, H, W = x.shape
@@ -255,7 +257,7 @@ def _composite(kind: str, fields: Sequence[str]):
             tensors = {n: (None if p is None else _require(p, f"{kind} {n}")) for n, p in zip(fields, params)}
             desc = make_desc(B, C, H, W, heads, hidden, ln_with_bias, conv_bias)
             par = _fill(BlockParams(), tensors)
-            need_grad = any(ctx.needs_input_grad)   # grad mode is off inside Function.forward
+            need_grad = bool(keep)
             saved = None
             if need_grad:
                 nbytes = getattr(lib, f"rst_{kind}_saved_bytes")(ctypes.byref(desc))
@@ -295,7 +297,7 @@ def _composite(kind: str, fields: Sequence[str]):
                 st = fn(ctypes.byref(desc), ctypes.byref(par), _ptr(x), _ptr(dy), _ptr(saved), _ptr(dx), 0, ctypes.byref(gr),
                         _ptr(ws), ws.numel(), _stream())
             check(st, bwd_name)
-            return (dx, None, None, None, None) + tuple(grads[n] for n in fields)
+            return (dx, None, None, None, None, None) + tuple(grads[n] for n in fields)
 
     Fn.__name__ = f"_{kind.capitalize()}Fn"
     return Fn
@@ -306,15 +308,24 @@ _FfnFn = _composite("ffn", FFN_FIELDS)
 _BlockFn = _composite("block", PARAM_FIELDS)
 
 
+def _keep(x, params) -> bool:
+    """True when autograd will record the call.  This has to be decided outside
+    Function.forward: inside it grad mode is always off, and ctx.needs_input_grad
+    stays True for parameters even under torch.no_grad()."""
+    return torch.is_grad_enabled() and (x.requires_grad or any(p is not None and p.requires_grad for p in params))
+
+
 def attention(x, heads, temperature, qkv_weight, qkv_bias, qkv_dw_weight, qkv_dw_bias, proj_weight, proj_bias):
     """MDTA (reference: Attention.forward, model/Restromer.py:127-150)."""
-    return _AttentionFn.apply(x, heads, 1, True, qkv_bias is not None,
+    ps = (temperature, qkv_weight, qkv_bias, qkv_dw_weight, qkv_dw_bias, proj_weight, proj_bias)
+    return _AttentionFn.apply(x, heads, 1, True, qkv_bias is not None, _keep(x, ps),
                               temperature, qkv_weight, qkv_bias, qkv_dw_weight, qkv_dw_bias, proj_weight, proj_bias)
 
 
 def feed_forward(x, hidden, pin_weight, pin_bias, dw_weight, dw_bias, pout_weight, pout_bias):
     """GDFN (reference: FeedForward.forward, model/Restromer.py:99-104)."""
-    return _FfnFn.apply(x, 1, hidden, True, pin_bias is not None,
+    ps = (pin_weight, pin_bias, dw_weight, dw_bias, pout_weight, pout_bias)
+    return _FfnFn.apply(x, 1, hidden, True, pin_bias is not None, _keep(x, ps),
                         pin_weight, pin_bias, dw_weight, dw_bias, pout_weight, pout_bias)
 
 
@@ -323,7 +334,8 @@ def transformer_block(x, heads, hidden, params: Dict[str, Optional[torch.Tensor]
     the names in PARAM_FIELDS to tensors (None for absent biases)."""
     ln_with_bias = params.get("norm1_bias") is not None
     conv_bias = params.get("qkv_bias") is not None
-    return _BlockFn.apply(x, heads, hidden, ln_with_bias, conv_bias, *[params.get(n) for n in PARAM_FIELDS])
+    ps = [params.get(n) for n in PARAM_FIELDS]
+    return _BlockFn.apply(x, heads, hidden, ln_with_bias, conv_bias, _keep(x, ps), *ps)
 
 
 def block_forward_inplace(x, heads, hidden, params: Dict[str, Optional[torch.Tensor]]):

@@ -108,6 +108,32 @@ def bench_gram():
         print(f"wgrad {label} (3C x C) {us:8.1f} us {fl / us / 1e6:6.1f} TFLOP/s {by / us / 1e3:7.1f} GB/s")
 
 
+def bench_block():
+    """Per-kernel times of one inference block at the level shapes of the dim=48 network."""
+    import ctypes, json
+    from superresolution_amd import ops
+    from superresolution_amd.model.Restromer import TransformerBlock
+    lib = _lib.load()
+    for (B, C, heads, H) in [(16, 48, 1, 256), (16, 96, 1, 256), (16, 96, 2, 128), (16, 192, 4, 64), (16, 384, 8, 32)]:
+        blk = TransformerBlock(C, heads, 1.25, False, "WithBias").cuda()
+        x = torch.rand(B, C, H, H, device="cuda")
+        par = blk._params()
+        for _ in range(2):
+            ops.block_forward_inplace(x, heads, blk.ffn.hidden_features, par)
+        torch.cuda.synchronize()
+        reps = 5
+        lib.rst_profile_begin()
+        for _ in range(reps):
+            ops.block_forward_inplace(x, heads, blk.ffn.hidden_features, par)
+        torch.cuda.synchronize()
+        buf = ctypes.create_string_buffer(1 << 16)
+        lib.rst_profile_end(buf, len(buf))
+        prof = json.loads(buf.value.decode())
+        tot = sum(v["ms"] for v in prof.values()) / reps
+        print(f"block B={B} C={C} H={H}: {tot*1e3:8.1f} us  " +
+              "  ".join(f"{k}={v['ms']/reps*1e3:.0f}" for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['ms'])))
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("gemm", "all"):
@@ -116,6 +142,8 @@ if __name__ == "__main__":
         bench_dw()
     if what in ("ln", "all"):
         bench_ln()
+    if what in ("block", "all"):
+        bench_block()
     if what in ("lnbwd", "all"):
         bench_lnbwd()
     if what in ("gram", "all"):
