@@ -68,3 +68,25 @@ def test_submodules_backward_vs_oracle(case):
             ref = s[name + "." + k].grad
             err = float((p.grad.double().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-30))
             assert err < TOL, (tag, name, k, err)
+
+
+@pytest.mark.parametrize("case", [recipe.BLOCK_CASES[0], recipe.BLOCK_CASES[3], recipe.BLOCK_CASES[6]],
+                         ids=lambda c: c[0])
+@pytest.mark.parametrize("offset", [0.0, 6.0])
+def test_inference_folded_layernorm_vs_oracle(case, offset):
+    """Inference folds both LayerNorms into the following products and takes mean and variance
+    in one pass; a channel mean far from zero (offset / sigma ~ 12) is where a one-pass variance
+    loses digits, so the block is checked there against the fp64 oracle at the same tolerance."""
+    from oracle import restormer_oracle as orc
+    tag, dim, heads, ln_type, bias, b, h, w = case
+    blk, x, _ = _block(case)
+    sd64, x64, _ = recipe.block_case_tensors(case, torch.float64)
+    x = x * 0.5 + offset
+    x64 = x64 * 0.5 + offset
+    with torch.no_grad():
+        got = blk(x)
+    ref = orc.transformer_block(x64, sd64, "", heads)
+    # the residual keeps the offset in the output: measure the error against the size of the update
+    upd = (ref - x64).abs().max()
+    err = float((got.double().cpu() - ref).abs().max() / upd)
+    assert err < TOL, (tag, offset, err)
