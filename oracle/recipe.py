@@ -65,6 +65,13 @@ BLOCK_CASES = [
     ("c384h8_wb_nb", 384, 8, "WithBias", False, 1, 4, 6),
     ("c24h2_wb_b", 24, 2, "WithBias", True, 2, 5, 7),      # ragged: odd H, W, tiny channels
     ("c12h1_bf_nb", 12, 1, "BiasFree", False, 1, 3, 9),
+    # wide rows (W >= 64): the shapes of the high-resolution levels, where inference runs the fused
+    # 1x1 + depthwise kernel -- two column strips with a ragged second one, both strip widths,
+    # conv and depthwise biases, both LayerNorm flavours, odd H, two samples
+    ("c48h1_wb_nb_w136", 48, 1, "WithBias", False, 1, 12, 136),
+    ("c96h1_bf_b_w72", 96, 1, "BiasFree", True, 1, 9, 72),
+    ("c96h2_wb_b_w128", 96, 2, "WithBias", True, 2, 20, 128),
+    ("c48h1_wb_nb_w64", 48, 1, "WithBias", False, 2, 33, 64),
 ]
 FFN_FACTOR = 1.25
 

@@ -86,6 +86,35 @@ static int ln_conv1x1(const LnIn& ln, const float* w, const float* bias, int Cou
     return gemm_nn_launch(g, stream);
 }
 
+// y = dw3x3(conv1x1(LN(x)))  or, with `hidden` > 0, gelu(d[:hidden]) * d[hidden:] of that -- one fused
+// kernel when the shape allows (inference only: nothing is kept for a backward pass).
+// Returns true in *done when the fused kernel ran.
+static int ln_pw_dw(const LnIn* ln, const float* w, const float* bias, const float* dw_w, const float* dw_b,
+                    int Cout, int Cin, int hidden, const float* x, float* y, int B, int H, int W, float* fold,
+                    hipStream_t stream, bool* done) {
+    *done = false;
+    const int64_t N = (int64_t)H * W;
+    PwDw a{};
+    a.X = x; a.x_bs = (int64_t)Cin * N;
+    a.dw_w = dw_w; a.dw_b = dw_b;
+    a.Y = y; a.y_bs = (int64_t)(hidden > 0 ? hidden : Cout) * N;
+    a.B = B; a.K = Cin; a.M = Cout; a.H = H; a.W = W;
+    a.gate = hidden > 0 ? 1 : 0; a.hidden = hidden;
+    a.A = w; a.ln_mode = 0; a.ln_s = nullptr; a.ln_c = bias;
+    // RST_FUSE_PWDW=1 forces the fused kernel wherever it is supported (tests, experiments)
+    static const bool force = getenv("RST_FUSE_PWDW") != nullptr && getenv("RST_FUSE_PWDW")[0] == '1';
+    if (!(force ? pwdw_supported(a) : pwdw_profitable(a))) return RST_OK;
+    if (ln) {
+        float* s = fold + (size_t)Cout * Cin;
+        float* c = s + Cout;
+        RST_TRY(ln_fold_weights_launch(w, ln->gamma, ln->beta, bias, Cout, Cin, fold, s, c, stream));
+        a.A = fold; a.ln_mode = ln->beta ? 1 : 2; a.ln_s = s; a.ln_c = c;
+    }
+    RST_TRY(pwdw_launch(a, stream));
+    *done = true;
+    return RST_OK;
+}
+
 // dW[M1][M2] = sum_b A[b] Bm[b]^T through split-K partials in `ws`
 static size_t wgrad_ws_floats(int M1, int M2, int64_t N, int B) {
     const NtPlan p = gemm_nt_plan(M1, M2, N, B);
@@ -168,18 +197,24 @@ static int attention_fwd(const rst_block_desc* d, const rst_block_params* p, con
     attn_carve_ws(d, saved != nullptr, cw, b);
 
     // t = W_qkv x (+bias);  qkv = dw3x3(t)
-    if (ln) {
-        RST_TRY(ln_conv1x1(*ln, p->qkv_weight, d->conv_bias ? p->qkv_bias : nullptr, 3 * C, C, x, b.t, B, N, b.fold, stream));
-    } else {
-        GemmNN g1 = conv1x1_args(p->qkv_weight, 3 * C, C, false, x, b.t, B, N);
-        g1.bias = d->conv_bias ? p->qkv_bias : nullptr;
-        RST_TRY(gemm_nn_launch(g1, stream));
+    bool fused = false;
+    if (!saved)
+        RST_TRY(ln_pw_dw(ln, p->qkv_weight, d->conv_bias ? p->qkv_bias : nullptr, p->qkv_dw_weight,
+                         d->conv_bias ? p->qkv_dw_bias : nullptr, 3 * C, C, 0, x, b.qkv, B, d->H, d->W, b.fold, stream, &fused));
+    if (!fused) {
+        if (ln) {
+            RST_TRY(ln_conv1x1(*ln, p->qkv_weight, d->conv_bias ? p->qkv_bias : nullptr, 3 * C, C, x, b.t, B, N, b.fold, stream));
+        } else {
+            GemmNN g1 = conv1x1_args(p->qkv_weight, 3 * C, C, false, x, b.t, B, N);
+            g1.bias = d->conv_bias ? p->qkv_bias : nullptr;
+            RST_TRY(gemm_nn_launch(g1, stream));
+        }
+        DwArgs dw{};
+        dw.x = b.t; dw.x_bstride = (int64_t)3 * C * N; dw.w = p->qkv_dw_weight;
+        dw.bias = d->conv_bias ? p->qkv_dw_bias : nullptr;
+        dw.y = b.qkv; dw.y_bstride = (int64_t)3 * C * N; dw.B = B; dw.C = 3 * C; dw.H = d->H; dw.W = d->W; dw.flip = 0;
+        RST_TRY(dwconv_fwd_launch(dw, stream));
     }
-    DwArgs dw{};
-    dw.x = b.t; dw.x_bstride = (int64_t)3 * C * N; dw.w = p->qkv_dw_weight;
-    dw.bias = d->conv_bias ? p->qkv_dw_bias : nullptr;
-    dw.y = b.qkv; dw.y_bstride = (int64_t)3 * C * N; dw.B = B; dw.C = 3 * C; dw.H = d->H; dw.W = d->W; dw.flip = 0;
-    RST_TRY(dwconv_fwd_launch(dw, stream));
 
     // Gram matrices and squared row norms, split over the pixels
     GemmNT gt{};
@@ -356,18 +391,24 @@ static int ffn_fwd(const rst_block_desc* d, const rst_block_params* p, const flo
     }
     const int B = d->B, C = d->C, Hd = d->hidden;
     const int64_t N = (int64_t)d->H * d->W;
-    if (ln) {
-        RST_TRY(ln_conv1x1(*ln, p->pin_weight, d->conv_bias ? p->pin_bias : nullptr, 2 * Hd, C, x, b.u, B, N, fold, stream));
-    } else {
-        GemmNN g1 = conv1x1_args(p->pin_weight, 2 * Hd, C, false, x, b.u, B, N);
-        g1.bias = d->conv_bias ? p->pin_bias : nullptr;
-        RST_TRY(gemm_nn_launch(g1, stream));
+    bool fused = false;
+    if (!saved)
+        RST_TRY(ln_pw_dw(ln, p->pin_weight, d->conv_bias ? p->pin_bias : nullptr, p->ffn_dw_weight,
+                         d->conv_bias ? p->ffn_dw_bias : nullptr, 2 * Hd, C, Hd, x, b.g, B, d->H, d->W, fold, stream, &fused));
+    if (!fused) {
+        if (ln) {
+            RST_TRY(ln_conv1x1(*ln, p->pin_weight, d->conv_bias ? p->pin_bias : nullptr, 2 * Hd, C, x, b.u, B, N, fold, stream));
+        } else {
+            GemmNN g1 = conv1x1_args(p->pin_weight, 2 * Hd, C, false, x, b.u, B, N);
+            g1.bias = d->conv_bias ? p->pin_bias : nullptr;
+            RST_TRY(gemm_nn_launch(g1, stream));
+        }
+        GateArgs ga{};
+        ga.u = b.u; ga.u_bstride = (int64_t)2 * Hd * N; ga.w = p->ffn_dw_weight; ga.bias = d->conv_bias ? p->ffn_dw_bias : nullptr;
+        ga.gout = b.g; ga.g_bstride = (int64_t)Hd * N; ga.d = b.d; ga.d_bstride = (int64_t)2 * Hd * N;
+        ga.B = B; ga.hidden = Hd; ga.H = d->H; ga.W = d->W;
+        RST_TRY(dwconv_gate_fwd_launch(ga, stream));
     }
-    GateArgs ga{};
-    ga.u = b.u; ga.u_bstride = (int64_t)2 * Hd * N; ga.w = p->ffn_dw_weight; ga.bias = d->conv_bias ? p->ffn_dw_bias : nullptr;
-    ga.gout = b.g; ga.g_bstride = (int64_t)Hd * N; ga.d = b.d; ga.d_bstride = (int64_t)2 * Hd * N;
-    ga.B = B; ga.hidden = Hd; ga.H = d->H; ga.W = d->W;
-    RST_TRY(dwconv_gate_fwd_launch(ga, stream));
     GemmNN g2 = conv1x1_args(p->pout_weight, C, Hd, false, b.g, y, B, N);
     g2.bias = d->conv_bias ? p->pout_bias : nullptr;
     g2.R = residual; g2.r_s1 = (int64_t)C * N; g2.r_s2 = 0; g2.ldr = N;

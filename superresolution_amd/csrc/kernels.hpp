@@ -41,6 +41,22 @@ bool gemm_nn_ln_supported(const GemmNN& g);
 int ln_fold_weights_launch(const float* w, const float* gamma, const float* beta, const float* bias, int M, int K,
                            float* folded, float* s, float* c, hipStream_t stream);
 
+// ---- pwdw.hip: 1x1 convolution (+ folded LayerNorm) fused with the 3x3 depthwise convolution ----
+struct PwDw {
+    const float* X; int64_t x_bs;        // [B][K][H][W]
+    const float* A;                      // [M][K]; W o gamma when ln_mode != 0
+    int ln_mode;                         // as GemmNN::ln_mode; 0: plain product, ln_c (may be null) is the conv bias
+    const float* ln_s; const float* ln_c;
+    const float* dw_w;                   // [M][9]
+    const float* dw_b;                   // [M] or null
+    float* Y; int64_t y_bs;              // [B][M][H][W], or [B][hidden][H][W] with gate
+    int B, K, M, H, W;
+    int gate, hidden;                    // gate: M == 2*hidden, Y = gelu(d[:hidden]) * d[hidden:]
+};
+bool pwdw_supported(const PwDw& a);
+bool pwdw_profitable(const PwDw& a);      // supported and measured faster than the unfused pair
+int pwdw_launch(const PwDw& a, hipStream_t stream);
+
 // ---- gemm_nt.hip ----
 struct GemmNT {
     const float* A; int64_t a_s1, a_s2; int64_t lda;

@@ -1,0 +1,447 @@
+// Y = dw3x3(W1 * LN(X))            (qkv path of the attention,  reference model/Restromer.py:130-131,116-124)
+// Y = gelu(d[:Hd]) * d[Hd:],  d = dw3x3(W1 * LN(X))     (gated FFN input, model/Restromer.py:100-103,87-95)
+// in ONE kernel for the high-resolution levels: the 1x1 product never goes to memory.
+//
+// Decomposition.  A block owns a column strip of 64 pixels of one sample, a range of rows, and NW
+// slabs of 16 output channels; it walks DOWN the rows.  Wave w owns slab w for the whole strip:
+//   * its 16 weight rows sit in LDS in MFMA operand form (one float per lane and k-step) for the
+//     whole launch;
+//   * per row, the K input channels of the strip (plus four pixels either side) stream through a
+//     3-deep LDS ring in chunks of 24 channels, filled by LDS-DMA only; the wave multiplies its
+//     slab into 4 accumulator tiles of 16 pixels (v_mfma_f32_16x16x4_f32, exact fp32);
+//   * the two halo columns (one pixel left and right of the strip) are plain dot products on the
+//     vector ALU, taken from the same ring -- a fifth MFMA tile for two columns would cost 25 %;
+//   * the finished row of the 1x1 output stays in registers.  The product is formed with the
+//     pixels as MFMA rows, so a lane holds ONE channel and four consecutive pixels per tile:
+//     the depthwise weights are nine scalars per lane, the horizontal taps are neighbouring
+//     registers (the pixel before the first and after the fourth comes from the neighbouring
+//     lane group, tile, or halo column), and stores are float4.  The rows above and below
+//     enter through two running partial sums per output tile (row r adds its share to output
+//     rows r-1, r, r+1; row r-1 is then complete and leaves for memory).
+// The first and last row of a row range are recomputed by the neighbouring block (no exchange).
+//
+// LayerNorm in front of the product is folded as in gemm_nn (A = W o gamma, ln_s, ln_c): the
+// per-pixel mean / variance over the K channels are taken from the LDS ring while the chunks
+// pass (the waves share the 80 ring columns, results go through LDS once per row).
+// Pixels outside the image are forced to zero AFTER the bias / LayerNorm constants, because the
+// depthwise filter pads its input -- the 1x1 output -- with zeros.
+//
+// GATE: waves w and w + NW/2 hold channel c of the two halves; each hands the other half of its
+// finished tiles over through LDS, so both apply gelu(a) * b to half of the strip.
+#include "kernels.hpp"
+
+namespace rst {
+
+typedef __attribute__((address_space(1))) const void* pw_gptr;
+typedef __attribute__((address_space(3))) void* pw_lptr;
+typedef float pw_f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int PW_T = 4;                  // MFMA tiles per strip row
+constexpr int PW_WT = 16 * PW_T;         // strip width
+constexpr int PW_CPR = 20;               // 16-byte pieces per channel row in LDS: 4 px halo + 64 + 4 px halo, padded
+constexpr int PW_ROWF = PW_CPR * 4;      // == 16 (mod 64): the four k-rows of an operand read hit disjoint banks
+constexpr int PW_CK = 24;                // channels per ring stage (one barrier per 24 channels: 24 MFMAs per wave)
+constexpr int PW_NINSTR = (PW_CK * PW_CPR + 63) / 64;   // wave-wide DMA instructions per chunk (8; the last one is half used)
+constexpr int PW_XCH = PW_NINSTR * 256;  // floats per ring stage (>= PW_CK * PW_ROWF)
+constexpr int PW_NSG = PW_ROWF / 16;     // groups of 16 ring columns for the statistics (5)
+
+// QLDS: the running sum of the row below (see header) lives in LDS instead of registers.
+template <int KS, int NW, bool GATE, bool QLDS>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GATE ? 2 : 3, GATE ? 2 : 3)))
+pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
+    constexpr int T = PW_T, WT = PW_WT, ROWF = PW_ROWF, XCH = PW_XCH;
+    constexpr int P = (PW_NINSTR + NW - 1) / NW;     // DMA instructions per wave per chunk (surplus ones land in a dummy area)
+    constexpr int CKS = PW_CK / 4;                   // k-steps per chunk
+    constexpr int NC = KS / CKS;                     // chunks per row
+    static_assert(KS % CKS == 0, "K must be a multiple of the chunk depth");
+    static_assert(PW_XCH >= PW_CK * PW_ROWF, "ring stage too small");
+    constexpr int NTW = (PW_NSG + NW - 1) / NW;      // statistics groups per wave
+    constexpr int PAIRS = NW / 2, HT = T / 2;
+    extern __shared__ __attribute__((aligned(16))) float pw_smem[];
+    float* ring = pw_smem;                               // 3 stages + 256 floats for surplus DMA pieces
+    float* statm = ring + 3 * XCH + 256;                 // [80] minus mean (or 0) per ring column
+    float* statr = statm + ROWF;                         // [80] 1/sqrt(var + eps)
+    float* xch = statr + ROWF;                           // GATE: [PAIRS][2][HT][64] float4 hand-over area
+    float* qbuf = xch + (GATE ? PAIRS * 2 * HT * 256 : 0);   // QLDS: [NW][T][64] float4
+    float* wlds = qbuf + (QLDS ? NW * T * 256 : 0);      // [NW][KS][64] weights as MFMA B operand
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lm = lane & 15, kk = lane >> 4;
+    const int H = a.H, W = a.W;
+    const int64_t HW = (int64_t)H * W;
+
+    // blocks 8 apart share an XCD (and its L2): the G channel groups of one strip are placed there
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int g = slot % G;
+    const int col = (slot / G) * 8 + xcd;
+    if (col >= ncols) return;
+    const int sp = col % nsplit, strip = (col / nsplit) % nstrips, b = col / (nsplit * nstrips);
+    const int px0 = strip * WT;
+    const int R0 = (int)((int64_t)H * sp / nsplit), R1 = (int)((int64_t)H * (sp + 1) / nsplit);
+    const int ra = R0 > 0 ? R0 - 1 : 0, rb = R1 < H ? R1 : H - 1;
+
+    // ---- this lane's channel: plain: ch of M;  gate: channel ch of half `half` (row half*hidden + ch) ----
+    const int half = GATE ? wave / PAIRS : 0;
+    const int ch = (GATE ? (g * PAIRS + wave % PAIRS) * 16 : (g * NW + wave) * 16) + lm;
+    const int chlim = GATE ? a.hidden : a.M;
+    const bool chok = ch < chlim;
+    const int wrow = (GATE ? half * a.hidden : 0) + (chok ? ch : 0);
+
+    // weights of the channel as MFMA B operand: lane (n = channel, k = kk), k-step s at mywl[s * 64]
+    float* mywl = wlds + wave * KS * 64 + lane;
+    {
+        const float* Ar = a.A + (int64_t)wrow * a.K;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) mywl[s * 64] = chok ? Ar[4 * s + kk] : 0.f;
+    }
+    float wv[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wv[t] = chok ? a.dw_w[(int64_t)wrow * 9 + t] : 0.f;
+    const float lns = (chok && a.ln_s) ? a.ln_s[wrow] : 0.f;
+    const float lnc = (chok && a.ln_c) ? a.ln_c[wrow] : 0.f;
+    const float bq = (chok && a.dw_b) ? a.dw_b[wrow] : 0.f;
+
+    // ---- DMA pieces of this wave: ring column c holds pixel px0 - 4 + c ----
+    const char* Xb = reinterpret_cast<const char*>(a.X + (int64_t)b * a.x_bs);
+    unsigned srcoff[P];                                  // bytes from the chunk's first channel row
+    int dstoff[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int i = wave + p * NW;
+        if (i < PW_NINSTR) {
+            const int e = 64 * i + lane;
+            const int k = e / PW_CPR < PW_CK ? e / PW_CPR : PW_CK - 1, cc = e % PW_CPR;      // tail of the last instruction: any valid address
+            const int px = px0 - 4 + 4 * cc;
+            srcoff[p] = 4u * ((unsigned)(k * HW) + ((px >= 0 && px < W) ? px : 0));     // out-of-image pieces read a valid address and are masked later
+            dstoff[p] = 256 * i;
+        } else {
+            srcoff[p] = 0;
+            dstoff[p] = -1;
+        }
+    }
+    // chunk q of the block's stream: row ra + q / NC, channels (q % NC) * 48 ..; lands in ring stage q % 3
+    const int nq = (rb - ra + 1) * NC;
+    auto issue = [&](int q, int stage) {
+        const int row = ra + q / NC, c = q % NC;
+        const char* src = Xb + 4 * ((int64_t)c * PW_CK * HW + (int64_t)row * W);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            float* dst = dstoff[p] >= 0 ? ring + stage * XCH + dstoff[p] : ring + 3 * XCH;
+            __builtin_amdgcn_global_load_lds((pw_gptr)(src + srcoff[p]), (pw_lptr)dst, 16, 0, 0);
+        }
+    };
+
+    // accumulator layout (operands swapped: pixels are the MFMA rows): register q of tile j is pixel
+    // px0 + 16*j + 4*kk + q of this lane's channel
+    float* Yb = a.Y + (int64_t)b * a.y_bs + (int64_t)(chok ? ch : 0) * HW;
+    const f32x4 bq4 = {bq, bq, bq, bq};
+    constexpr int QN = QLDS ? 1 : T;
+    f32x4 Pst[T], Qst[QN], acc[T];
+    f32x4* myq = reinterpret_cast<f32x4*>(qbuf) + (QLDS ? wave * T * 64 + lane : 0);     // + j * 64
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        Pst[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (QLDS) myq[j * 64] = bq4; else Qst[j] = bq4;
+    }
+    constexpr int HN = GATE ? HT : 1;
+    f32x4 hold[HN];
+    int pend_row = -1;
+    f32x4* myx = reinterpret_cast<f32x4*>(xch) + (GATE ? ((wave % PAIRS) * 2 + half) * HT * 64 + lane : 0);        // handed over by this wave
+    const f32x4* ptx = reinterpret_cast<const f32x4*>(xch) + (GATE ? ((wave % PAIRS) * 2 + (1 - half)) * HT * 64 + lane : 0);
+
+    // finished output tile `j` of row `row`: 4 consecutive pixels of one channel per lane
+    auto store_tile = [&](const f32x4& v, int row, int j) {
+        const int px = px0 + 16 * j + 4 * kk;
+        if (chok && px < W) *reinterpret_cast<f32x4*>(Yb + (int64_t)row * W + px) = v;
+    };
+    auto stash = [&](const f32x4& v, int j) {           // GATE: keep my half of the strip, hand the other half over
+        const bool mine = (j < HT) == (half == 0);
+        if (mine) hold[j % HN] = v;
+        else myx[(j % HN) * 64] = v;
+    };
+    auto finalize = [&](int row) {                      // GATE: gelu(first half) * second half on my tiles
+#pragma unroll
+        for (int jh = 0; jh < HN; ++jh) {
+            const f32x4 other = ptx[jh * 64];
+            f32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float x1 = half == 0 ? hold[jh][q] : other[q];
+                const float x2 = half == 0 ? other[q] : hold[jh][q];
+                o[q] = gelu_erf(x1) * x2;
+            }
+            store_tile(o, row, half * HT + jh);
+        }
+    };
+    // byte addresses (for ds_bpermute) of the lanes that hold the previous / next 4 pixels of the channel
+    const int nbr_next = ((lane + 16) & 63) * 4, nbr_prev = ((lane + 48) & 63) * 4;
+    const bool in_l = px0 - 1 >= 0, in_r = px0 + WT < W;
+
+    issue(0, 0);
+    issue(nq > 1 ? 1 : 0, 1);
+    int qc = 0, stage_c = 0;                             // chunk being consumed and its stage
+
+    for (int r = ra; r <= rb; ++r) {
+#pragma unroll
+        for (int j = 0; j < T; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float hl = 0.f, hr = 0.f;                        // halo columns: this lane's k share of the dot products
+        pw_f32x2 st[NTW];
+#pragma unroll
+        for (int jj = 0; jj < NTW; ++jj) st[jj] = pw_f32x2{0.f, 0.f};
+
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            // chunk qc has landed for this wave (the next chunk's P pieces may still be in flight), then
+            // for everyone; the barrier also frees the stage that is refilled next
+            // (lgkmcnt: LDS writes of the previous phase -- the GATE hand-over -- are visible after the barrier)
+            if constexpr (P == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else if constexpr (P == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            static_assert(P == 1 || P == 2 || P == 3, "wait count");
+            {
+                const int qn = qc + 2 < nq ? qc + 2 : nq - 1;       // past the end: keeps the per-wave count fixed, rewrites identical data
+                issue(qn, qn % 3);
+            }
+            if constexpr (GATE) {
+                if (c == 0 && pend_row >= 0) { finalize(pend_row); pend_row = -1; }
+            }
+            const float* Xc = ring + stage_c * XCH + kk * ROWF;
+            const float* wc = mywl + c * CKS * 64;
+            // operands of a k-step: the four tile columns, the two halo columns and the weight.  The
+            // loop is rolled and carries the operands of the next two steps across its back edge, so
+            // every LDS read is issued two steps (8 MFMAs) before its use and cannot be sunk.
+            struct Ops { float x[6]; float w; };
+            auto fetch = [&](int s, Ops& o) {
+#pragma unroll
+                for (int j = 0; j < T; ++j) o.x[j] = Xc[4 * s * ROWF + 4 + 16 * j + lm];
+                o.x[4] = Xc[4 * s * ROWF + 3];
+                o.x[5] = Xc[4 * s * ROWF + 4 + WT];
+                o.w = wc[s * 64];
+            };
+            auto use = [&](const Ops& o) {
+#pragma unroll
+                for (int j = 0; j < T; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.x[j], o.w, acc[j], 0, 0, 0);
+                hl = fmaf(o.w, o.x[4], hl);
+                hr = fmaf(o.w, o.x[5], hr);
+            };
+            Ops oa, ob;
+            fetch(0, oa);
+            fetch(1, ob);
+            static_assert(CKS % 2 == 0, "the k loop handles two steps per trip");
+#pragma unroll 1
+            for (int s = 0; s < CKS; s += 2) {
+                // the last trip fetches two steps past the chunk: in-bounds (the ring has a tail), never used
+                Ops na, nb;
+                use(oa);
+                fetch(s + 2, na);
+                use(ob);
+                fetch(s + 3, nb);
+                oa = na;
+                ob = nb;
+            }
+            if (a.ln_mode != 0) {
+#pragma unroll
+                for (int jj = 0; jj < NTW; ++jj) {
+                    const int sg = wave + jj * NW;
+                    if (sg < PW_NSG) {
+#pragma unroll
+                        for (int s = 0; s < CKS; ++s) {
+                            const float x = Xc[4 * s * ROWF + 16 * sg + lm];
+                            st[jj] += pw_f32x2{x, x * x};
+                        }
+                    }
+                }
+            }
+            ++qc;
+            stage_c = stage_c == 2 ? 0 : stage_c + 1;
+        }
+
+        // ---- per-pixel LayerNorm constants of the row, shared through LDS ----
+        if (a.ln_mode != 0) {
+#pragma unroll
+            for (int jj = 0; jj < NTW; ++jj) {
+                const int sg = wave + jj * NW;
+                if (sg < PW_NSG) {
+                    float s1 = st[jj][0], s2 = st[jj][1];
+                    s1 += __shfl_xor(s1, 16); s2 += __shfl_xor(s2, 16);
+                    s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+                    const float mu = s1 * (1.0f / (4 * KS));
+                    const float var = fmaxf(s2 * (1.0f / (4 * KS)) - mu * mu, 0.f);
+                    if (kk == 0) {
+                        statm[16 * sg + lm] = a.ln_mode == 1 ? -mu : 0.f;
+                        statr[16 * sg + lm] = 1.0f / sqrtf(var + 1e-5f);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        // halo columns: add the four k shares, then constants and mask like every other pixel
+        hl += __shfl_xor(hl, 16); hr += __shfl_xor(hr, 16);
+        hl += __shfl_xor(hl, 32); hr += __shfl_xor(hr, 32);
+        {
+            float tl = 0.f, rl = 1.f, tr = 0.f, rr = 1.f;
+            if (a.ln_mode != 0) { tl = statm[3]; rl = statr[3]; tr = statm[4 + WT]; rr = statr[4 + WT]; }
+            hl = in_l ? fmaf(rl, fmaf(tl, lns, hl), lnc) : 0.f;
+            hr = in_r ? fmaf(rr, fmaf(tr, lns, hr), lnc) : 0.f;
+        }
+        // 1x1 output of a tile: LayerNorm constants and bias, then zero outside the image
+        auto finish_tile = [&](int j) {
+            const int px = px0 + 16 * j + 4 * kk;
+            f32x4 tco = {0.f, 0.f, 0.f, 0.f}, rstd = {1.f, 1.f, 1.f, 1.f};
+            if (a.ln_mode != 0) {
+                tco = *reinterpret_cast<const f32x4*>(&statm[4 + 16 * j + 4 * kk]);
+                rstd = *reinterpret_cast<const f32x4*>(&statr[4 + 16 * j + 4 * kk]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float v = fmaf(rstd[q], fmaf(tco[q], lns, acc[j][q]), lnc);
+                acc[j][q] = px < W ? v : 0.f;             // W % 4 == 0: the four pixels are inside or outside together
+            }
+        };
+        finish_tile(0);
+
+        // ---- depthwise 3x3: this row's share of output rows r-1 (now complete), r and r+1 ----
+        const bool emit = r - 1 >= R0 && r - 1 < R1;
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            if (j + 1 < T) finish_tile(j + 1);
+            // e[0..5]: the pixel before the tile's four, the four, and the one after
+            float e[6];
+            {
+                const float same = __int_as_float(__builtin_amdgcn_ds_bpermute(nbr_prev, __float_as_int(acc[j][3])));
+                const float other = j > 0 ? __int_as_float(__builtin_amdgcn_ds_bpermute(nbr_prev, __float_as_int(acc[j > 0 ? j - 1 : 0][3]))) : hl;
+                e[0] = kk == 0 ? other : same;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) e[1 + q] = acc[j][q];
+            {
+                const float same = __int_as_float(__builtin_amdgcn_ds_bpermute(nbr_next, __float_as_int(acc[j][0])));
+                const float other = j + 1 < T ? __int_as_float(__builtin_amdgcn_ds_bpermute(nbr_next, __float_as_int(acc[j + 1 < T ? j + 1 : j][0]))) : hr;
+                e[5] = kk == 3 ? other : same;
+            }
+            f32x4 qold;
+            if constexpr (QLDS) qold = myq[j * 64]; else qold = Qst[j];
+            f32x4 done, pn, qn;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                done[q] = fmaf(wv[8], e[q + 2], fmaf(wv[7], e[q + 1], fmaf(wv[6], e[q], Pst[j][q])));
+                pn[q] = fmaf(wv[5], e[q + 2], fmaf(wv[4], e[q + 1], fmaf(wv[3], e[q], qold[q])));
+                qn[q] = fmaf(wv[2], e[q + 2], fmaf(wv[1], e[q + 1], fmaf(wv[0], e[q], bq)));
+            }
+            Pst[j] = pn;
+            if constexpr (QLDS) myq[j * 64] = qn; else Qst[j] = qn;
+            if (emit) {
+                if constexpr (GATE) stash(done, j);
+                else store_tile(done, r - 1, j);
+            }
+        }
+        if constexpr (GATE) { if (emit) pend_row = r - 1; }
+    }
+
+    // all DMA (including the surplus re-issues) must have landed before the block's LDS is released
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (GATE) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (pend_row >= 0) finalize(pend_row);
+    }
+    if (R1 == H) {
+        // bottom edge of the image: the row below is zero padding, so the running sum of the last row is final
+        if constexpr (GATE) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // partners are done reading the previous hand-over
+#pragma unroll
+            for (int j = 0; j < T; ++j) stash(Pst[j], j);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            finalize(H - 1);
+        } else {
+#pragma unroll
+            for (int j = 0; j < T; ++j) store_tile(Pst[j], H - 1, j);
+        }
+    }
+}
+
+// ---- host side ----
+struct PwPlan { int ks, nw, G, nstrips, nsplit, ncols; bool ok; };
+
+static PwPlan pwdw_plan(const PwDw& a) {
+    PwPlan p{};
+    p.ok = false;
+    if (a.K != 48 && a.K != 96) return p;           // compiled channel depths
+    if (a.W % 4 != 0 || a.W < 64 || a.H < 1) return p;
+    if (!aligned16(a.X) || a.x_bs % 4 != 0 || !aligned16(a.Y) || a.y_bs % 4 != 0) return p;
+    if ((int64_t)a.K * a.H * a.W >= (1ll << 30)) return p;          // byte offsets inside a sample stay below 2^32
+    if (a.gate && a.M != 2 * a.hidden) return p;
+    p.ks = a.K / 4;
+    p.nstrips = (int)cdiv(a.W, PW_WT);
+    if (a.gate) {
+        p.nw = 8;
+        p.G = (int)cdiv(cdiv(a.hidden, 16), 4);
+    } else {
+        const int slabs = (int)cdiv(a.M, 16);
+        const int pad6 = (int)cdiv(slabs, 6) * 6, pad3 = (int)cdiv(slabs, 3) * 3;
+        p.nw = pad6 <= pad3 ? 6 : 3;
+        p.G = (int)cdiv(slabs, p.nw);
+    }
+    p.ok = true;
+    return p;
+}
+
+bool pwdw_supported(const PwDw& a) { return pwdw_plan(a).ok; }
+
+// Measured on MI355X (16 x C x 256 x 256): at 48 input channels the fused kernel beats the
+// product + depthwise pair (365 vs 530 us for qkv, 400 vs 420 us gated); at 96 channels the pair
+// still wins (the fused kernel keeps the matrix pipe only ~30 % busy), so it stays opt-in there.
+bool pwdw_profitable(const PwDw& a) { return pwdw_plan(a).ok && a.K == 48; }
+
+int pwdw_launch(const PwDw& a, hipStream_t stream) {
+    PwPlan p = pwdw_plan(a);
+    RST_REQUIRE(p.ok, "pwdw: unsupported shape (K=%d W=%d)", a.K, a.W);
+    RST_REQUIRE(a.X && a.A && a.dw_w && a.Y && a.B > 0 && a.M > 0, "pwdw: bad operand");
+    RST_REQUIRE(a.ln_mode == 0 || (a.ln_s && a.ln_c), "pwdw: folded LayerNorm without its constants");
+
+    int dev = 0, cus = 256;
+    RST_HIP(hipGetDevice(&dev));
+    RST_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    const void* kern = nullptr;
+#define PW_KS(NWV, GT) do { if (p.ks == 12) kern = reinterpret_cast<const void*>(&pwdw_kernel<12, NWV, GT, false>); \
+                            else kern = reinterpret_cast<const void*>(&pwdw_kernel<24, NWV, GT, false>); } while (0)
+    if (a.gate) PW_KS(8, true);
+    else if (p.nw == 6) PW_KS(6, false);
+    else PW_KS(3, false);
+#undef PW_KS
+    const size_t lds = sizeof(float) * (size_t)(3 * PW_XCH + 256 + 2 * PW_ROWF +
+                                                (a.gate ? (p.nw / 2) * 2 * (PW_T / 2) * 256 : 0) + p.nw * p.ks * 64 + 256);
+    if (lds > 64 * 1024) RST_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 1;
+    RST_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, p.nw * 64, lds));
+    if (per_cu < 1) per_cu = 1;
+    // Split the rows of every (sample, strip, channel group) column so that the grid comes in whole
+    // rounds of resident blocks; every row range recomputes two halo rows, so weigh that against
+    // the fill of the last round.
+    const int64_t cols0 = (int64_t)a.B * p.nstrips;
+    const int64_t slots = (int64_t)cus * per_cu;
+    int nsplit = 1;
+    double best = -1.0;
+    for (int ns = 1; ns <= (a.H >= 16 ? a.H / 8 : 1); ++ns) {
+        const int64_t blocks = cols0 * p.G * ns;
+        const int64_t rounds = cdiv(blocks, slots);
+        const double rows = (double)a.H / ns;
+        const double eff = (double)blocks / (double)(rounds * slots) * rows / (rows + 2.0);
+        if (eff > best + 1e-9) { best = eff; nsplit = ns; }
+    }
+    p.nsplit = nsplit;
+    const int64_t ncols = cols0 * nsplit;
+    RST_REQUIRE(ncols * p.G < (1ll << 30), "pwdw: grid too large");
+    p.ncols = (int)ncols;
+    const int64_t cols8 = cdiv(ncols, 8) * 8;
+    const unsigned grid = (unsigned)(cols8 * p.G);
+
+    const double N = (double)a.B * a.H * a.W;
+    ProfScope prof(stream, a.gate ? "pwdw_gate" : "pwdw", 2.0 * a.M * a.K * N + 18.0 * a.M * N,
+                   4.0 * N * (a.K + (a.gate ? a.hidden : a.M)));
+    void* args[] = {(void*)&a, (void*)&p.nstrips, (void*)&p.nsplit, (void*)&p.G, (void*)&p.ncols};
+    RST_HIP(hipLaunchKernel(kern, dim3(grid), dim3(p.nw * 64), args, lds, stream));
+    RST_LAUNCH_CHECK();
+    return RST_OK;
+}
+
+}  // namespace rst
