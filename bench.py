@@ -102,7 +102,23 @@ def kernel_profile(run_once):
     return json.loads(buf.value.decode())
 
 
-def roofline_from(prof):
+def measured_traffic(name, batch, size, mode):
+    """HBM bytes per launch of kernel group `name`, from the committed rocprofv3 --pmc run of this
+    same workload (profiles/r1_b_hbm_traffic.json; FETCH_SIZE and WRITE_SIZE collected in separate
+    passes, FETCH_SIZE doubled as gfx950 requires).  None for any other workload or kernel."""
+    path = os.path.join(ROOT, "profiles", "r1_b_hbm_traffic.json")
+    try:
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    c = d.get("config", {})
+    if (c.get("batch"), c.get("size"), c.get("mode")) != (batch, size, mode):
+        return None
+    k = d.get("kernels", {}).get(name)
+    return None if k is None else k.get("bytes_per_launch")
+
+
+def roofline_from(prof, traffic_of=lambda name: None):
     name = max(prof, key=lambda k: prof[k]["ms"])
     k = prof[name]
     sec = k["ms"] * 1e-3
@@ -115,7 +131,7 @@ def roofline_from(prof):
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": round(achieved / PEAK_HBM_GBS, 4)}
     roof.update({"kernel": name, "launches_per_step": k["launches"], "avg_launch_us": round(k["ms"] * 1e3 / k["launches"], 2),
-                 "traffic": None})
+                 "traffic": traffic_of(name), "algorithmic_bytes_per_launch": round(k["bytes"] / k["launches"])})
     total = sum(v["ms"] for v in prof.values())
     breakdown = {n: {"ms": round(v["ms"], 3), "share": round(v["ms"] / total, 3),
                      "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1), "TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
@@ -205,7 +221,7 @@ def main():
     }
     if rank == 0:
         prof = kernel_profile(step)
-        roof, breakdown, ktotal = roofline_from(prof)
+        roof, breakdown, ktotal = roofline_from(prof, lambda name: measured_traffic(name, B, S, args.mode))
         out["roofline"] = roof
         out["kernels"] = breakdown
         out["hip_kernel_ms_per_step"] = round(ktotal, 3)
