@@ -102,31 +102,29 @@ attn_fold_kernel(const float* __restrict__ wo,      // [C][C]
 
 // ---- backward ---------------------------------------------------------------------
 // One wave per row i of one (b,h); grid = (ceil(c/4), B*heads), block 256.
-//   dA_ij   = sum_m Wo[m][hc+i] * P[b][m][hc+j]
+//   dA_ij   = sum_m Wo[m][hc+i] * P[b][m][hc+j]   -- a (c x C)(C x c) product per (b,h), formed by
+//             gemm_nn beforehand and handed over in the dGG buffer (overwritten in place here)
 //   dS_ij   = A_ij * (dA_ij - sum_j dA_ij A_ij)
 //   dtemp  += sum_ij dS_ij * Ghat_ij ;  dGhat = dS * temperature
 //   Eq_ij   = dGhat_ij / (nq_i nk_j)              (dq_i = sum_j Eq_ij k_j + Dq_i q_i)
 //   Dq_i    = -(sum_j dGhat_ij Ghat_ij) / nq_i^2  (0 where the norm was clamped)
 //   dGG_ij  = dGhat_ij * Ghat_ij                  (column sums give Dk)
 __global__ void __launch_bounds__(256)
-attn_bwd_rows_kernel(const float* __restrict__ P, const float* __restrict__ wo, const float* __restrict__ attn,
+attn_bwd_rows_kernel(const float* __restrict__ attn,
                      const float* __restrict__ ghat, const float* __restrict__ nq, const float* __restrict__ nk,
                      const float* __restrict__ temperature,
-                     float* __restrict__ Eq, float* __restrict__ Dq, float* __restrict__ dGG, float* __restrict__ dtemp_row,
-                     int C, int heads, int c) {
+                     float* __restrict__ Eq, float* __restrict__ Dq, float* dGG, float* __restrict__ dtemp_row,
+                     int heads, int c) {
     extern __shared__ __attribute__((aligned(16))) float smem[];      // 4 rows x c
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int bh = blockIdx.y, b = bh / heads, h = bh % heads;
     const int i = blockIdx.x * 4 + wave;
     if (i >= c) return;
     float* row = smem + wave * c;
-    const float* Pb = P + (int64_t)b * C * C + h * c;
-    const float* wcol = wo + h * c + i;
     const int64_t rbase = ((int64_t)bh * c + i) * c;
     float rs = 0.f;
     for (int j = lane; j < c; j += 64) {
-        float s = 0.f;
-        for (int m = 0; m < C; ++m) s = fmaf(wcol[(int64_t)m * C], Pb[(int64_t)m * C + j], s);
+        const float s = dGG[rbase + j];
         row[j] = s;
         rs = fmaf(s, attn[rbase + j], rs);
     }
@@ -198,13 +196,22 @@ int attn_bwd_small_launch(const float* P, const float* wo, const float* attn, co
                           const float* nk, const float* temperature, float* Eq, float* Dq, float* Dk, float* dGG,
                           float* dtemp_row, float* dtemp_b, float* dwo_b, int B, int C, int heads, int c,
                           hipStream_t stream) {
-    ProfScope prof(stream, "attn_bwd_small", 6.0 * B * C * C * c, 4.0 * B * (3.0 * C * C + 6.0 * heads * c * c));
+    {
+        // dA[b,h] = Wo[:, h-slice]^T P[b][:, h-slice] into dGG
+        GemmNN g{};
+        g.A = wo; g.a_s1 = 0; g.a_s2 = c; g.lda = C; g.transA = 1;
+        g.X = P; g.x_s1 = (int64_t)C * C; g.x_s2 = c; g.ldx = C;
+        g.Y = dGG; g.y_s1 = (int64_t)heads * c * c; g.y_s2 = (int64_t)c * c; g.ldy = c;
+        g.M = c; g.K = C; g.N = c; g.nb1 = B; g.nb2 = heads;
+        RST_TRY(gemm_nn_launch(g, stream));
+    }
+    ProfScope prof(stream, "attn_bwd_small", 2.0 * B * C * C * c, 4.0 * B * (3.0 * C * C + 6.0 * heads * c * c));
     {
         const size_t lds = (size_t)4 * c * sizeof(float);
         RST_REQUIRE(lds <= 64 * 1024, "attention: channels per head %d too large", c);
         dim3 grid((unsigned)cdiv(c, 4), (unsigned)(B * heads));
-        hipLaunchKernelGGL(attn_bwd_rows_kernel, grid, dim3(256), lds, stream, P, wo, attn, ghat, nq, nk, temperature,
-                           Eq, Dq, dGG, dtemp_row, C, heads, c);
+        hipLaunchKernelGGL(attn_bwd_rows_kernel, grid, dim3(256), lds, stream, attn, ghat, nq, nk, temperature,
+                           Eq, Dq, dGG, dtemp_row, heads, c);
         RST_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(attn_bwd_cols_kernel, dim3((unsigned)(B * heads)), dim3(256), 0, stream, dGG, nk, dtemp_row, Dk,

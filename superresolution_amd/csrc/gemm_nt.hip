@@ -409,6 +409,40 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ partial, float* __
     *dst = accumulate ? (*dst + s) : s;
 }
 
+// Same sum for elems % 4 == 0: a block covers 128 elements with 32 float4 columns x 8 slab lanes;
+// lane l adds slabs l, l+8, ... in order, then the 8 lanes are added in order through LDS.
+__global__ void __launch_bounds__(256)
+reduce_slabs_vec_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                        int64_t elems, int slabs_per_group, int accumulate) {
+    __shared__ f32x4 red[8][32];
+    const int col = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int64_t e = ((int64_t)blockIdx.x * 32 + col) * 4;
+    const int64_t grp = blockIdx.y;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (e < elems) {
+        const float* p = partial + grp * slabs_per_group * elems + e;
+        int i = sl;
+        for (; i + 24 < slabs_per_group; i += 32) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p + (int64_t)i * elems);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(p + (int64_t)(i + 8) * elems);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(p + (int64_t)(i + 16) * elems);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(p + (int64_t)(i + 24) * elems);
+            s += a; s += b; s += c; s += d;
+        }
+        for (; i < slabs_per_group; i += 8) s += *reinterpret_cast<const f32x4*>(p + (int64_t)i * elems);
+    }
+    red[sl][col] = s;
+    __syncthreads();
+    if (sl == 0 && e < elems) {
+        f32x4 t = red[0][col];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k][col];
+        f32x4* dst = reinterpret_cast<f32x4*>(out + grp * elems + e);
+        if (accumulate) t += *dst;
+        *dst = t;
+    }
+}
+
 // Tile plan along one output dimension: 16*T rows per wave, W waves.
 static NtDim nt_pick_dim(int M, int maxW) {
     NtDim best{1, 1, (int)cdiv(M, 16)};
@@ -508,7 +542,12 @@ int reduce_slabs_launch(const float* partial, float* out, int64_t elems, int gro
     dim3 gd((unsigned)cdiv(elems, 256), (unsigned)groups), blk(256);
     ProfScope prof(stream, "reduce_slabs", (double)elems * groups * slabs_per_group,
                    4.0 * elems * groups * (slabs_per_group + 1.0));
-    hipLaunchKernelGGL(reduce_slabs_kernel, gd, blk, 0, stream, partial, out, elems, slabs_per_group, accumulate);
+    if (elems % 4 == 0 && aligned16(partial) && aligned16(out)) {
+        dim3 gv((unsigned)cdiv(elems, 128), (unsigned)groups);
+        hipLaunchKernelGGL(reduce_slabs_vec_kernel, gv, blk, 0, stream, partial, out, elems, slabs_per_group, accumulate);
+    } else {
+        hipLaunchKernelGGL(reduce_slabs_kernel, gd, blk, 0, stream, partial, out, elems, slabs_per_group, accumulate);
+    }
     RST_LAUNCH_CHECK();
     return RST_OK;
 }
