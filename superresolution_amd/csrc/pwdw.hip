@@ -7,7 +7,7 @@
 //   * its 16 weight rows sit in LDS in MFMA operand form (one float per lane and k-step) for the
 //     whole launch;
 //   * per row, the K input channels of the strip (plus four pixels either side) stream through a
-//     3-deep LDS ring in chunks of 24 channels, filled by LDS-DMA only; the wave multiplies its
+//     5-deep LDS ring in chunks of 24 channels, filled by LDS-DMA only; the wave multiplies its
 //     slab into 4 accumulator tiles of 16 pixels (v_mfma_f32_16x16x4_f32, exact fp32);
 //   * the two halo columns (one pixel left and right of the strip) are plain dot products on the
 //     vector ALU, taken from the same ring -- a fifth MFMA tile for two columns would cost 25 %;
@@ -43,6 +43,7 @@ constexpr int PW_ROWF = PW_CPR * 4;      // == 16 (mod 64): the four k-rows of a
 constexpr int PW_CK = 24;                // channels per ring stage (one barrier per 24 channels: 24 MFMAs per wave)
 constexpr int PW_NINSTR = (PW_CK * PW_CPR + 63) / 64;   // wave-wide DMA instructions per chunk (8; the last one is half used)
 constexpr int PW_XCH = PW_NINSTR * 256;  // floats per ring stage (>= PW_CK * PW_ROWF)
+constexpr int PW_STAGES = 5;             // ring depth: chunks q+1 .. q+4 stream in while chunk q is multiplied
 constexpr int PW_NSG = PW_ROWF / 16;     // groups of 16 ring columns for the statistics (5)
 
 // QLDS: the running sum of the row below (see header) lives in LDS instead of registers.
@@ -58,8 +59,8 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
     constexpr int NTW = (PW_NSG + NW - 1) / NW;      // statistics groups per wave
     constexpr int PAIRS = NW / 2, HT = T / 2;
     extern __shared__ __attribute__((aligned(16))) float pw_smem[];
-    float* ring = pw_smem;                               // 3 stages + 256 floats for surplus DMA pieces
-    float* statm = ring + 3 * XCH + 256;                 // [80] minus mean (or 0) per ring column
+    float* ring = pw_smem;                               // PW_STAGES stages + 256 floats for surplus DMA pieces
+    float* statm = ring + PW_STAGES * XCH + 256;                 // [80] minus mean (or 0) per ring column
     float* statr = statm + ROWF;                         // [80] 1/sqrt(var + eps)
     float* xch = statr + ROWF;                           // GATE: [PAIRS][2][HT][64] float4 hand-over area
     float* qbuf = xch + (GATE ? PAIRS * 2 * HT * 256 : 0);   // QLDS: [NW][T][64] float4
@@ -119,14 +120,14 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
             dstoff[p] = -1;
         }
     }
-    // chunk q of the block's stream: row ra + q / NC, channels (q % NC) * 48 ..; lands in ring stage q % 3
+    // chunk q of the block's stream: row ra + q / NC, channels (q % NC) * 48 ..; lands in ring stage q % PW_STAGES
     const int nq = (rb - ra + 1) * NC;
     auto issue = [&](int q, int stage) {
         const int row = ra + q / NC, c = q % NC;
         const char* src = Xb + 4 * ((int64_t)c * PW_CK * HW + (int64_t)row * W);
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            float* dst = dstoff[p] >= 0 ? ring + stage * XCH + dstoff[p] : ring + 3 * XCH;
+            float* dst = dstoff[p] >= 0 ? ring + stage * XCH + dstoff[p] : ring + PW_STAGES * XCH;
             __builtin_amdgcn_global_load_lds((pw_gptr)(src + srcoff[p]), (pw_lptr)dst, 16, 0, 0);
         }
     };
@@ -177,8 +178,8 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
     const int nbr_next = ((lane + 16) & 63) * 4, nbr_prev = ((lane + 48) & 63) * 4;
     const bool in_l = px0 - 1 >= 0, in_r = px0 + WT < W;
 
-    issue(0, 0);
-    issue(nq > 1 ? 1 : 0, 1);
+#pragma unroll
+    for (int i = 0; i < PW_STAGES - 1; ++i) issue(i < nq ? i : nq - 1, i);
     int qc = 0, stage_c = 0;                             // chunk being consumed and its stage
 
     for (int r = ra; r <= rb; ++r) {
@@ -194,51 +195,62 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
             // chunk qc has landed for this wave (the next chunk's P pieces may still be in flight), then
             // for everyone; the barrier also frees the stage that is refilled next
             // (lgkmcnt: LDS writes of the previous phase -- the GATE hand-over -- are visible after the barrier)
-            if constexpr (P == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else if constexpr (P == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // (PW_STAGES - 2) newer chunks of P pieces each may still be in flight
+            static_assert(PW_STAGES == 5, "wait counts below are for three newer chunks");
+            if constexpr (P == 1) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else if constexpr (P == 2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             static_assert(P == 1 || P == 2 || P == 3, "wait count");
             {
-                const int qn = qc + 2 < nq ? qc + 2 : nq - 1;       // past the end: keeps the per-wave count fixed, rewrites identical data
-                issue(qn, qn % 3);
+                const int qn = qc + PW_STAGES - 1 < nq ? qc + PW_STAGES - 1 : nq - 1;   // past the end: keeps the per-wave count fixed, rewrites identical data
+                issue(qn, qn % PW_STAGES);
             }
             if constexpr (GATE) {
                 if (c == 0 && pend_row >= 0) { finalize(pend_row); pend_row = -1; }
             }
             const float* Xc = ring + stage_c * XCH + kk * ROWF;
-            const float* wc = mywl + c * CKS * 64;
-            // operands of a k-step: the four tile columns, the two halo columns and the weight.  The
-            // loop is rolled and carries the operands of the next two steps across its back edge, so
-            // every LDS read is issued two steps (8 MFMAs) before its use and cannot be sunk.
-            struct Ops { float x[6]; float w; };
-            auto fetch = [&](int s, Ops& o) {
-#pragma unroll
-                for (int j = 0; j < T; ++j) o.x[j] = Xc[4 * s * ROWF + 4 + 16 * j + lm];
-                o.x[4] = Xc[4 * s * ROWF + 3];
-                o.x[5] = Xc[4 * s * ROWF + 4 + WT];
-                o.w = wc[s * 64];
-            };
-            auto use = [&](const Ops& o) {
-#pragma unroll
-                for (int j = 0; j < T; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.x[j], o.w, acc[j], 0, 0, 0);
-                hl = fmaf(o.w, o.x[4], hl);
-                hr = fmaf(o.w, o.x[5], hr);
-            };
-            Ops oa, ob;
-            fetch(0, oa);
-            fetch(1, ob);
-            static_assert(CKS % 2 == 0, "the k loop handles two steps per trip");
-#pragma unroll 1
-            for (int s = 0; s < CKS; s += 2) {
-                // the last trip fetches two steps past the chunk: in-bounds (the ring has a tail), never used
-                Ops na, nb;
-                use(oa);
-                fetch(s + 2, na);
-                use(ob);
-                fetch(s + 3, nb);
-                oa = na;
-                ob = nb;
-            }
+            // Operands of a k-step: the four tile columns, the two halo columns and the weight = four
+            // LDS reads.  They are issued by hand two steps (8 MFMAs) ahead of their use: left to the
+            // compiler, every read is sunk next to its MFMA and the matrix pipe waits for each LDS
+            // round trip.  LDS reads return in order, so "at most 8 newer reads outstanding" means the
+            // reads of the step being multiplied have landed; the wait names the operand registers
+            // so that the MFMAs cannot be scheduled above it.
+            const unsigned tb = (unsigned)(uintptr_t)(pw_lptr)(Xc + lm);       // tile columns of this lane
+            const unsigned hb = (unsigned)(uintptr_t)(pw_lptr)Xc;              // halo columns (same for 16 lanes)
+            const unsigned wb = (unsigned)(uintptr_t)(pw_lptr)(mywl + c * CKS * 64);
+            pw_f32x2 x01[3], x23[3], xh[3];
+            float wq[3];
+#define PW_FETCH(S)                                                                                             \
+            do {                                                                                                \
+                constexpr int SET = (S) % 3;                                                                    \
+                const unsigned tbs = tb + (S) * 4 * ROWF * 4, hbs = hb + (S) * 4 * ROWF * 4;                   \
+                asm volatile("ds_read2_b32 %0, %1 offset0:4 offset1:20" : "=v"(x01[SET]) : "v"(tbs));          \
+                asm volatile("ds_read2_b32 %0, %1 offset0:36 offset1:52" : "=v"(x23[SET]) : "v"(tbs));         \
+                asm volatile("ds_read2_b32 %0, %1 offset0:3 offset1:68" : "=v"(xh[SET]) : "v"(hbs));           \
+                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(wq[SET]) : "v"(wb), "n"((S) * 256));         \
+            } while (0)
+#define PW_USE(S, NEWER)                                                                                        \
+            do {                                                                                                \
+                constexpr int SET = (S) % 3;                                                                    \
+                asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(x01[SET]), "+v"(x23[SET]), "+v"(xh[SET]), "+v"(wq[SET]) : "n"(NEWER)); \
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x01[SET][0], wq[SET], acc[0], 0, 0, 0);           \
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x01[SET][1], wq[SET], acc[1], 0, 0, 0);           \
+                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(x23[SET][0], wq[SET], acc[2], 0, 0, 0);           \
+                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(x23[SET][1], wq[SET], acc[3], 0, 0, 0);           \
+                hl = fmaf(wq[SET], xh[SET][0], hl);                                                             \
+                hr = fmaf(wq[SET], xh[SET][1], hr);                                                             \
+            } while (0)
+            static_assert(CKS == 6 && T == 4 && WT == 64, "the hand-scheduled k loop is written for 6 steps of 4 tiles");
+            PW_FETCH(0);
+            PW_FETCH(1);
+            PW_FETCH(2); PW_USE(0, 8);
+            PW_FETCH(3); PW_USE(1, 8);
+            PW_FETCH(4); PW_USE(2, 8);
+            PW_FETCH(5); PW_USE(3, 8);
+            PW_USE(4, 4);
+            PW_USE(5, 0);
+#undef PW_FETCH
+#undef PW_USE
             if (a.ln_mode != 0) {
 #pragma unroll
                 for (int jj = 0; jj < NTW; ++jj) {
@@ -253,7 +265,7 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
                 }
             }
             ++qc;
-            stage_c = stage_c == 2 ? 0 : stage_c + 1;
+            stage_c = stage_c == PW_STAGES - 1 ? 0 : stage_c + 1;
         }
 
         // ---- per-pixel LayerNorm constants of the row, shared through LDS ----
@@ -388,8 +400,9 @@ static PwPlan pwdw_plan(const PwDw& a) {
 bool pwdw_supported(const PwDw& a) { return pwdw_plan(a).ok; }
 
 // Measured on MI355X (16 x C x 256 x 256): at 48 input channels the fused kernel beats the
-// product + depthwise pair (365 vs 530 us for qkv, 400 vs 420 us gated); at 96 channels the pair
-// still wins (the fused kernel keeps the matrix pipe only ~30 % busy), so it stays opt-in there.
+// product + depthwise pair (about 400 vs 530 us for qkv, 390 vs 420 us gated); at 96 channels the
+// two are level (1230 vs 1210 us, 970 vs 980 us): the streaming of the input rows, the MFMA phase
+// and the depthwise phase still run back to back instead of overlapping, so it stays opt-in there.
 bool pwdw_profitable(const PwDw& a) { return pwdw_plan(a).ok && a.K == 48; }
 
 int pwdw_launch(const PwDw& a, hipStream_t stream) {
@@ -408,7 +421,7 @@ int pwdw_launch(const PwDw& a, hipStream_t stream) {
     else if (p.nw == 6) PW_KS(6, false);
     else PW_KS(3, false);
 #undef PW_KS
-    const size_t lds = sizeof(float) * (size_t)(3 * PW_XCH + 256 + 2 * PW_ROWF +
+    const size_t lds = sizeof(float) * (size_t)(PW_STAGES * PW_XCH + 256 + 2 * PW_ROWF +
                                                 (a.gate ? (p.nw / 2) * 2 * (PW_T / 2) * 256 : 0) + p.nw * p.ks * 64 + 256);
     if (lds > 64 * 1024) RST_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 1;
