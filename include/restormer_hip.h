@@ -135,6 +135,19 @@ int rst_conv1x1_bwd(const float* x, const float* weight, const float* dy,
                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* Dense 3x3 convolution, zero padding 1, with 1..4 output channels and an     */
+/* optional residual added to the result -- replaces the network's last layer  */
+/* `self.output` (nn.Conv2d(dim, out_channels, 3, padding=1),                  */
+/* model/Restromer.py:381-383) and the `+ base` that follows it (:431).        */
+/* x: [B, Cin, H, W]; weight: [Cout, Cin, 3, 3]; bias: [Cout] or NULL;         */
+/* residual, y: [B, Cout, H, W] (residual may be NULL; y may alias residual).  */
+/* Forward only: the Python mirror differentiates it with torch's own          */
+/* convolution gradients.                                                      */
+/* ------------------------------------------------------------------------- */
+int rst_conv3x3_fewout_fwd(const float* x, const float* weight, const float* bias, const float* residual, float* y,
+                           int32_t B, int32_t Cin, int32_t Cout, int32_t H, int32_t W, void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* Depthwise 3x3, zero padding 1 -- replaces qkv_dwconv / dwconv,             */
 /* model/Restromer.py:87-95,116-124.  x, y: [B, C, H, W]; weight: [C, 9].     */
 /* ------------------------------------------------------------------------- */

@@ -636,6 +636,13 @@ int rst_dwconv3x3_fwd(const float* x, const float* weight, const float* bias, fl
     a.y = y; a.y_bstride = (int64_t)C * H * W; a.B = B; a.C = C; a.H = H; a.W = W; a.flip = 0;
     return dwconv_fwd_launch(a, static_cast<hipStream_t>(stream));
 }
+int rst_conv3x3_fewout_fwd(const float* x, const float* weight, const float* bias, const float* residual, float* y,
+                           int32_t B, int32_t Cin, int32_t Cout, int32_t H, int32_t W, void* stream) {
+    Conv3Args a{};
+    a.x = x; a.w = weight; a.bias = bias; a.res = residual; a.y = y;
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+    return conv3x3_fewout_launch(a, static_cast<hipStream_t>(stream));
+}
 size_t rst_dwconv3x3_bwd_workspace_bytes(int32_t B, int32_t C, int32_t H, int32_t W) {
     return dwconv_bwd_weight_ws_bytes(B, C, H, W);
 }

@@ -120,6 +120,80 @@ dwconv_fwd_kernel(DwArgs a, int strips_x, int strips_y, int64_t total) {
     store_strip<VEC>(a.y + (int64_t)b * a.y_bstride + (int64_t)c * a.H * a.W, o, s.y0, s.x0, a.H, a.W);
 }
 
+// Dense 3x3 convolution with very few output channels (the network's last layer, 48 -> 3 at twice the
+// input resolution; reference model/Restromer.py:381-383) plus the residual that follows it (:431).
+// HBM-bound like the depthwise kernels (every input plane is read once, the output is small), so it
+// reuses their work item: a strip of 4 pixels x 4 rows, here of ALL output channels of one sample.
+// The input planes are walked one after the other; the 9*COUT weights of a plane are wave-uniform
+// (scalar loads), the COUT*16 running sums stay in registers.
+template <int COUT, bool VEC>
+__global__ void __launch_bounds__(256)
+conv3x3_fewout_kernel(Conv3Args a, int strips_x, int strips_y, int64_t total) {
+    const int lane = threadIdx.x & 63;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const Strip s = decode_strip(idx, total, strips_x, strips_y);      // plane index = sample
+    const int b = (int)s.plane;
+    const int64_t hw = (int64_t)a.H * a.W;
+    float o[COUT][DW_ROWS][4];
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+        const float bv = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+        for (int r = 0; r < DW_ROWS; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[co][r][j] = bv;
+    }
+    // the next input plane is fetched while the current one is multiplied
+    float in[DW_ROWS + 2][6], nxt[DW_ROWS + 2][6];
+    {
+        const float* xp = a.x + (int64_t)b * a.Cin * hw;
+#pragma unroll
+        for (int r = 0; r < DW_ROWS + 2; ++r) load_row6<VEC>(in[r], xp, s.y0 - 1 + r, s.x0, a.H, a.W, s.active, lane);
+    }
+    for (int ci = 0; ci < a.Cin; ++ci) {
+        {
+            const int cn = ci + 1 < a.Cin ? ci + 1 : ci;
+            const float* xp = a.x + ((int64_t)b * a.Cin + cn) * hw;
+#pragma unroll
+            for (int r = 0; r < DW_ROWS + 2; ++r) load_row6<VEC>(nxt[r], xp, s.y0 - 1 + r, s.x0, a.H, a.W, s.active, lane);
+        }
+#pragma unroll
+        for (int co = 0; co < COUT; ++co) {
+            const float* wk = a.w + ((int64_t)co * a.Cin + ci) * 9;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float k = wk[dy * 3 + dx];
+#pragma unroll
+                    for (int r = 0; r < DW_ROWS; ++r)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) o[co][r][j] = fmaf(in[r + dy][j + dx], k, o[co][r][j]);
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < DW_ROWS + 2; ++r)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) in[r][j] = nxt[r][j];
+    }
+    if (!s.active) return;
+#pragma unroll
+    for (int co = 0; co < COUT; ++co) {
+        const int64_t off = ((int64_t)b * COUT + co) * hw;
+        if (a.res != nullptr) {
+#pragma unroll
+            for (int r = 0; r < DW_ROWS; ++r) {
+                const int yy = s.y0 + r;
+                if (yy >= a.H) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (s.x0 + j < a.W) o[co][r][j] += a.res[off + (int64_t)yy * a.W + s.x0 + j];
+            }
+        }
+        store_strip<VEC>(a.y + off, o[co], s.y0, s.x0, a.H, a.W);
+    }
+}
+
 // GDFN gate: g[c] = gelu(dw(u[c])) * dw(u[c + hidden]), c < hidden
 // (model/Restromer.py:101-102).  Optionally keeps the two depthwise outputs
 // (d, [B][2*hidden][H][W]) for the backward pass.
@@ -334,6 +408,27 @@ int dwconv_bwd_weight_launch(const float* x, int64_t x_bstride, const float* dy,
     RST_LAUNCH_CHECK();
     hipLaunchKernelGGL(dwconv_bwd_weight_reduce_kernel, dim3((unsigned)cdiv(C * 10, 256)), dim3(256), 0, stream,
                        partial, splits, C, dweight, dbias);
+    RST_LAUNCH_CHECK();
+    return RST_OK;
+}
+
+int conv3x3_fewout_launch(const Conv3Args& a, hipStream_t stream) {
+    RST_REQUIRE(a.x && a.w && a.y, "conv3x3: null operand");
+    RST_REQUIRE(a.B > 0 && a.Cin > 0 && a.H > 0 && a.W > 0, "conv3x3: empty shape");
+    RST_REQUIRE(a.Cout >= 1 && a.Cout <= 4, "conv3x3: this kernel serves 1..4 output channels, got %d", a.Cout);
+    const int strips_x = (int)cdiv(a.W, 4), strips_y = (int)cdiv(a.H, DW_ROWS);
+    const int64_t total = (int64_t)a.B * strips_x * strips_y;
+    const bool vec = (a.W % 4 == 0) && aligned16(a.x) && aligned16(a.y);
+    dim3 grid((unsigned)cdiv(total, 256)), blk(256);
+    const double px = (double)a.B * a.H * a.W;
+    ProfScope prof(stream, "conv3x3_fewout", 18.0 * a.Cin * a.Cout * px, 4.0 * px * (a.Cin + a.Cout * (a.res ? 2.0 : 1.0)));
+#define C3_CASE(N)                                                                                              \
+    case N:                                                                                                     \
+        if (vec) hipLaunchKernelGGL((conv3x3_fewout_kernel<N, true>), grid, blk, 0, stream, a, strips_x, strips_y, total);  \
+        else     hipLaunchKernelGGL((conv3x3_fewout_kernel<N, false>), grid, blk, 0, stream, a, strips_x, strips_y, total); \
+        break;
+    switch (a.Cout) { C3_CASE(1) C3_CASE(2) C3_CASE(3) C3_CASE(4) }
+#undef C3_CASE
     RST_LAUNCH_CHECK();
     return RST_OK;
 }

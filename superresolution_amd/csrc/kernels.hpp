@@ -101,6 +101,17 @@ int dwconv_bwd_weight_launch(const float* x, int64_t x_bstride, const float* dy,
                              float* dweight, float* dbias, int B, int C, int H, int W,
                              void* ws, size_t ws_bytes, hipStream_t stream);
 
+// dense 3x3 convolution (zero padding 1) with 1..4 output channels, optional residual added to the result
+struct Conv3Args {
+    const float* x;          // [B][Cin][H][W]
+    const float* w;          // [Cout][Cin][3][3]
+    const float* bias;       // [Cout] or null
+    const float* res;        // [B][Cout][H][W] or null
+    float* y;                // [B][Cout][H][W]
+    int B, Cin, Cout, H, W;
+};
+int conv3x3_fewout_launch(const Conv3Args& a, hipStream_t stream);
+
 // ---- shuffle.hip ----
 int pixel_shuffle2_launch(bool shuffle, const float* src, float* dst, int B, int C, int H, int W, hipStream_t stream);
 

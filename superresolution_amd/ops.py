@@ -230,6 +230,50 @@ def pixel_shuffle2(x):
 
 
 # ----------------------------------------------------------------------------
+# dense 3x3 convolution with few output channels (+ residual): the last layer
+# ----------------------------------------------------------------------------
+class _Conv3x3FewOutFn(torch.autograd.Function):
+    """y = conv2d(x, weight, bias, padding=1) (+ residual) for 1..4 output channels
+    (reference: `self.output` and the `+ base` after it, model/Restromer.py:381-383,431).
+    Forward is the HIP kernel; the gradients are torch's convolution gradients."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual):
+        lib = _lib.load()
+        x = _require(x, "conv3x3 x")
+        w = _require(weight, "conv3x3 weight")
+        B, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        if tuple(w.shape) != (Cout, Cin, 3, 3):
+            raise RuntimeError(f"conv3x3: weight shape {tuple(w.shape)} does not match input channels {Cin}")
+        res = None if residual is None else _require(residual, "conv3x3 residual")
+        if res is not None and tuple(res.shape) != (B, Cout, H, W):
+            raise RuntimeError(f"conv3x3: residual shape {tuple(res.shape)} != {(B, Cout, H, W)}")
+        y = torch.empty((B, Cout, H, W), dtype=x.dtype, device=x.device)
+        check(lib.rst_conv3x3_fewout_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(res), _ptr(y), B, Cin, Cout, H, W, _stream()),
+              "rst_conv3x3_fewout_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.nn.grad.conv2d_input(x.shape, w, dy, padding=1) if ctx.needs_input_grad[0] else None
+        dw = torch.nn.grad.conv2d_weight(x, w.shape, dy, padding=1) if ctx.needs_input_grad[1] else None
+        db = dy.sum(dim=(0, 2, 3)) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        dr = dy if ctx.has_res and ctx.needs_input_grad[3] else None
+        return dx, dw, db, dr
+
+
+def conv3x3_fewout(x, weight, bias=None, residual=None):
+    """3x3 convolution, padding 1, at most 4 output channels, optional residual add."""
+    return _Conv3x3FewOutFn.apply(x, weight, bias, residual)
+
+
+# ----------------------------------------------------------------------------
 # composite operators: MDTA, GDFN, TransformerBlock
 # ----------------------------------------------------------------------------
 ATTN_FIELDS = ("temperature", "qkv_weight", "qkv_bias", "qkv_dw_weight", "qkv_dw_bias", "proj_weight", "proj_bias")

@@ -140,3 +140,28 @@ def test_errors_are_loud():
         ops.layernorm(torch.randn(1, 4, 2, 2, device="cuda").half(), torch.ones(4, device="cuda").half(), None)
     with pytest.raises(RuntimeError):
         ops.pixel_unshuffle2(torch.randn(1, 4, 3, 2, device="cuda"))
+
+
+@pytest.mark.parametrize("shape", [(2, 48, 3, 32, 40), (1, 12, 4, 9, 7), (2, 5, 1, 6, 10), (1, 24, 2, 64, 64), (1, 3, 4, 5, 5)])
+@pytest.mark.parametrize("bias", [False, True])
+@pytest.mark.parametrize("residual", [False, True])
+def test_conv3x3_fewout(shape, bias, residual):
+    """Last layer of the network: dense 3x3, few output channels, fused residual; forward through the
+    HIP kernel, gradients through torch's convolution gradients, both against the fp64 oracle."""
+    ops = _ops()
+    B, Cin, Cout, H, W = shape
+    x = _rand(B, Cin, H, W, seed=1)
+    w = _rand(Cout, Cin, 3, 3, seed=2) * 0.2
+    b = _rand(Cout, seed=3) if bias else None
+    r = _rand(B, Cout, H, W, seed=4) if residual else None
+    up = _rand(B, Cout, H, W, seed=5)
+    xo, wo = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref = orc.conv3x3(xo, wo, b) + (r if residual else 0.0)
+    (ref * up).sum().backward()
+    xg = x.float().cuda().requires_grad_(True)
+    wg = w.float().cuda().requires_grad_(True)
+    got = ops.conv3x3_fewout(xg, wg, None if b is None else b.float().cuda(), None if r is None else r.float().cuda())
+    (got * up.float().cuda()).sum().backward()
+    assert maxrel(got, ref) < TOL
+    assert maxrel(xg.grad, xo.grad) < 1e-4
+    assert maxrel(wg.grad, wo.grad) < 1e-4
