@@ -219,6 +219,8 @@ def main():
         "config": {"workload": workload, "global_batch": world * B, "input_hw": [S, S], "parallelism": f"dp{world}",
                    "weights": "default init, seed 0"},
     }
+    if rank != 0 and args.mode == "train":
+        step()          # the profiled extra step on rank 0 contains collectives: every rank takes part
     if rank == 0:
         prof = kernel_profile(step)
         roof, breakdown, ktotal = roofline_from(prof, lambda name: measured_traffic(name, B, S, args.mode))

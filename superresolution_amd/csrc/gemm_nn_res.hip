@@ -19,8 +19,10 @@
 
 namespace rst {
 
-constexpr int GR_BN = 128;
+constexpr int GR_BN = 64;                  // pixels per tile: 2 pixel halves x 32 per wave
+constexpr int GR_THREADS = 256;            // 4 waves = 2 row halves x 2 pixel halves; two such blocks share a CU
 constexpr int GR_SCR_LD = 36;                 // per-wave transpose scratch row stride (floats)
+constexpr int GR_SCRATCH = 4 * 2 * 16 * GR_SCR_LD;   // 4 waves x 2 slots; also the weight staging area (16 x (K+1) floats)
 // scratch = 4 waves x 16 x 36 floats = 2304 floats; as weight staging it holds 16 x (K+1) <= 16 x 121
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -28,17 +30,17 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int MT, int KS, bool RES, bool LN>
-__global__ void __launch_bounds__(512, 2)
+__global__ void __launch_bounds__(GR_THREADS, 2)
 gemm_nn_res_kernel(GemmNN g, int mblocks, int ntiles, int64_t total_tiles, int groups) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KROWS = 4 * KS;            // == K, checked by the launcher
     constexpr int BUF = KROWS * GR_BN;
-    float* scratch = smem + 2 * BUF;          // [8 waves][2 slots][16][GR_SCR_LD]
+    float* scratch = smem + 2 * BUF;          // [4 waves][2 slots][16][GR_SCR_LD]
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lm = lane & 15, kk = lane >> 4;
-    const int wn0 = (wave & 3) * 32;          // pixel quarter of this wave
-    const int mg = wave >> 2;                 // which half of the block's rows
+    const int wn0 = (wave & 1) * 32;          // pixel half of this wave
+    const int mg = wave >> 1;                 // which half of the block's rows
     // blocks 8 apart share an XCD: put the M-blocks of one pixel range there
     const int bid = blockIdx.x;
     const int rem = bid % (8 * mblocks);
@@ -52,11 +54,13 @@ gemm_nn_res_kernel(GemmNN g, int mblocks, int ntiles, int64_t total_tiles, int g
         const int64_t n0 = (t % ntiles) * GR_BN;
         const int b1 = (int)(bb / g.nb2), b2 = (int)(bb % g.nb2);
         const float* Xb = g.X + (int64_t)b1 * g.x_s1 + (int64_t)b2 * g.x_s2 + n0;
-        const int col = (lane & 31) * 4;
+        // LDS chunk c of sub-row j holds pixel chunk c ^ 4*(j&1): odd k-rows are stored with their two
+        // 16-pixel halves swapped, so the four k-rows of an operand read fall on disjoint banks
+        const int col = (((lane & 15) ^ (((lane >> 4) & 1) << 2))) * 4;
         const bool ok = n0 + col < g.N;       // N % 4 == 0
-        for (int p = wave; 2 * p < g.K; p += 8) {
-            const int row = 2 * p + (lane >> 5);
-            float* dst = smem + buf * BUF + 2 * p * GR_BN;          // wave-uniform base
+        for (int p = wave; 4 * p < g.K; p += GR_THREADS / 64) {        // one wave instruction = 4 channel rows of 64 pixels
+            const int row = 4 * p + (lane >> 4);
+            float* dst = smem + buf * BUF + 4 * p * GR_BN;          // wave-uniform base
             if (ok)
                 __builtin_amdgcn_global_load_lds((gptr_t)(Xb + (int64_t)row * g.ldx + col), (lptr_t)dst, 16, 0, 0);
         }
@@ -66,10 +70,10 @@ gemm_nn_res_kernel(GemmNN g, int mblocks, int ntiles, int64_t total_tiles, int g
     int64_t cur_b = -1;
     f32x4 acc[MT][2];
     // folded LayerNorm: per-row constants of the block's rows, kept in LDS behind the scratch
-    float* lnS = scratch + 16 * 16 * GR_SCR_LD;      // [32*MT] row sums, then [32*MT] row constants
+    float* lnS = scratch + GR_SCRATCH;      // [32*MT] row sums, then [32*MT] row constants
     float* lnC = lnS + 32 * MT;
     if constexpr (LN) {
-        for (int e = tid; e < 32 * MT; e += 512) {
+        for (int e = tid; e < 32 * MT; e += GR_THREADS) {
             const int m = mb * 32 * MT + e;
             const int mc = m < g.M ? m : g.M - 1;
             lnS[e] = g.ln_s[mc];
@@ -93,12 +97,12 @@ gemm_nn_res_kernel(GemmNN g, int mblocks, int ntiles, int64_t total_tiles, int g
             constexpr int K = 4 * KS;
             constexpr int SLD = K + 1;
             float* st = scratch;
-            static_assert(16 * SLD <= 16 * 16 * GR_SCR_LD, "staging area too small");
+            static_assert(16 * SLD <= GR_SCRATCH, "staging area too small");
             const int mblk = mb * 32 * MT;
 #pragma unroll 1
             for (int i2 = 0; i2 < 2 * MT; ++i2) {
                 __syncthreads();
-                for (int e = tid; e < 16 * K; e += 512) {
+                for (int e = tid; e < 16 * K; e += GR_THREADS) {
                     int r, k;
                     if (g.transA) { k = e >> 4; r = e & 15; } else { r = e / K; k = e - r * K; }
                     const int m = mblk + 16 * i2 + r;
@@ -148,14 +152,32 @@ gemm_nn_res_kernel(GemmNN g, int mblocks, int ntiles, int64_t total_tiles, int g
             acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
             acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        const float* Xs = smem + buf * BUF + wn0 + lm;
+        // B operands of a k-step: pixel columns wn0+lm and wn0+16+lm of k-row 4s+kk (halves swapped in
+        // odd k-rows, see issue_tile).  The two reads of step s+1 are issued by hand before the MFMAs of
+        // step s (the compiler would otherwise sink them next to their use and the matrix pipe would
+        // wait for each LDS round trip); LDS reads return in order, so lgkmcnt(2) = "step s has landed".
+        const int sw = (kk & 1) << 4;
+        const unsigned xa0 = (unsigned)(uintptr_t)(lptr_t)(smem + buf * BUF + kk * GR_BN + ((wn0 + lm) ^ sw));
+        const unsigned xa1 = (unsigned)(uintptr_t)(lptr_t)(smem + buf * BUF + kk * GR_BN + ((wn0 + 16 + lm) ^ sw));
+        float xq[2][2];
+#define GR_FETCH(S)                                                                                             \
+        do {                                                                                                    \
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(xq[(S) & 1][0]) : "v"(xa0), "n"((S) * 4 * GR_BN * 4)); \
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(xq[(S) & 1][1]) : "v"(xa1), "n"((S) * 4 * GR_BN * 4)); \
+        } while (0)
         // LayerNorm statistics of this wave's two pixel columns (sum and sum of squares over the
         // channels, two columns per packed instruction) ride along with the product
         f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+        GR_FETCH(0);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            const float x0 = Xs[(4 * s + kk) * GR_BN];
-            const float x1 = Xs[(4 * s + kk) * GR_BN + 16];
+            if (s + 1 < KS) {
+                GR_FETCH(s + 1);
+                asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xq[s & 1][0]), "+v"(xq[s & 1][1]));
+            } else {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xq[s & 1][0]), "+v"(xq[s & 1][1]));
+            }
+            const float x0 = xq[s & 1][0], x1 = xq[s & 1][1];
             if constexpr (LN) {
                 const f32x2 xv = {x0, x1};
                 s1 += xv;
@@ -168,13 +190,14 @@ gemm_nn_res_kernel(GemmNN g, int mblocks, int ntiles, int64_t total_tiles, int g
             }
         }
 
+#undef GR_FETCH
         // ---- epilogue: 16 x 32 tile -> wave-private LDS -> float4 rows ----
         float* Yb = g.Y + (int64_t)b1 * g.y_s1 + (int64_t)b2 * g.y_s2;
         // Two scratch slots per wave, software-pipelined: tile i+1 is written while tile i's rows
         // are still on their way back from LDS, so the LDS round trip hides behind the next
         // tile's writes instead of stalling every step.  (LDS operations of one wave complete in
         // issue order, so slot reuse two steps later needs no wait.)
-        float* scr = scratch + wave * 2 * 16 * GR_SCR_LD;   // 8 waves x 2 slots
+        float* scr = scratch + wave * 2 * 16 * GR_SCR_LD;   // 4 waves x 2 slots
         float rstd[2] = {1.f, 1.f}, tco[2] = {0.f, 0.f};
         if constexpr (LN) {
 #pragma unroll
@@ -276,10 +299,10 @@ int gemm_nn_res_try(const GemmNN& g, hipStream_t stream, bool* launched) {
     int dev = 0, cus = 256;
     RST_HIP(hipGetDevice(&dev));
     RST_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const size_t lds = (size_t)(2 * 4 * ksm * GR_BN + 16 * 16 * GR_SCR_LD + 2 * 32 * mt) * sizeof(float);
+    const size_t lds = (size_t)(2 * 4 * ksm * GR_BN + GR_SCRATCH + 2 * 32 * mt) * sizeof(float);   // scratch doubles as weight staging (16 x (K+1))
     int per_cu = 1;
     int groups = 0;
-    dim3 blk(512);
+    dim3 blk(GR_THREADS);
 
     const double nb = (double)g.nb1 * g.nb2;
     ProfScope prof(stream, g.ln_mode ? "gemm_nn_ln" : "gemm_nn", 2.0 * g.M * g.K * g.N * nb,
@@ -291,9 +314,9 @@ int gemm_nn_res_try(const GemmNN& g, hipStream_t stream, bool* launched) {
         if (lds > 64 * 1024)                                                                                  \
             RST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                  \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
-        RST_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 512, lds));                       \
+        RST_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, GR_THREADS, lds));                       \
         if (per_cu < 1) per_cu = 1;                                                                           \
-        if (per_cu > 1) per_cu = 1;                                                                           \
+        if (per_cu > 2) per_cu = 2;                                                                           \
         groups = cus * per_cu / mblocks;                                                                      \
         groups -= groups % 8;                                                                                 \
         if (groups > total) groups = (int)(total - total % 8);                                                \
