@@ -36,7 +36,7 @@ if ROOT not in sys.path:
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3    # MI355X v_mfma_f32_* dense peak
 PEAK_HBM_GBS = 8000.0              # MI355X HBM3E peak
-MFMA_KERNELS = {"gemm_nn", "gemm_nn_ln", "gemm_nt_splitk"}
+MFMA_KERNELS = {"gemm_nn", "gemm_nn_ln", "gemm_nt_splitk", "pwdw", "pwdw_gate"}
 
 
 def build_model(seed: int = 0):

@@ -101,9 +101,9 @@ static int ln_pw_dw(const LnIn* ln, const float* w, const float* bias, const flo
     a.B = B; a.K = Cin; a.M = Cout; a.H = H; a.W = W;
     a.gate = hidden > 0 ? 1 : 0; a.hidden = hidden;
     a.A = w; a.ln_mode = 0; a.ln_s = nullptr; a.ln_c = bias;
-    // RST_FUSE_PWDW=1 forces the fused kernel wherever it is supported (tests, experiments)
-    static const bool force = getenv("RST_FUSE_PWDW") != nullptr && getenv("RST_FUSE_PWDW")[0] == '1';
-    if (!(force ? pwdw_supported(a) : pwdw_profitable(a))) return RST_OK;
+    // RST_FUSE_PWDW=0 turns the fused kernel off (the product + depthwise pair runs instead): A/B runs, tests
+    static const bool off = getenv("RST_FUSE_PWDW") != nullptr && getenv("RST_FUSE_PWDW")[0] == '0';
+    if (off || !pwdw_profitable(a)) return RST_OK;
     if (ln) {
         float* s = fold + (size_t)Cout * Cin;
         float* c = s + Cout;

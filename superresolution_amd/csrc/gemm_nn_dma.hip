@@ -92,7 +92,7 @@ gemm_nn_dma_kernel(GemmNN g, int mblocks) {
     }
 
     // folded LayerNorm: sum and sum of squares over the channels of this wave's two pixel columns
-    gd_f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};     // plain (not packed) ALU ops: packed fp32 beside MFMAs costs extra issue time
 
     // per-row constants of the folded LayerNorm, fetched now and used in the epilogue
     constexpr int LNN = LN ? MTW : 1;
@@ -146,9 +146,8 @@ gemm_nn_dma_kernel(GemmNN g, int mblocks) {
         if constexpr (LN) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {      // rows past K were zeroed above
-                const gd_f32x2 xv = {bv[s][0], bv[s][1]};
-                s1 += xv;
-                s2 = __builtin_elementwise_fma(xv, xv, s2);
+                s1[0] += bv[s][0]; s2[0] = fmaf(bv[s][0], bv[s][0], s2[0]);
+                s1[1] += bv[s][1]; s2[1] = fmaf(bv[s][1], bv[s][1], s2[1]);
             }
         }
 #pragma unroll

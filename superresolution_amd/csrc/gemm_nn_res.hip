@@ -167,7 +167,7 @@ gemm_nn_res_kernel(GemmNN g, int mblocks, int ntiles, int64_t total_tiles, int g
         } while (0)
         // LayerNorm statistics of this wave's two pixel columns (sum and sum of squares over the
         // channels, two columns per packed instruction) ride along with the product
-        f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};
+        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};     // plain (not packed) ALU ops: packed fp32 beside MFMAs costs extra issue time
         GR_FETCH(0);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -179,9 +179,8 @@ gemm_nn_res_kernel(GemmNN g, int mblocks, int ntiles, int64_t total_tiles, int g
             }
             const float x0 = xq[s & 1][0], x1 = xq[s & 1][1];
             if constexpr (LN) {
-                const f32x2 xv = {x0, x1};
-                s1 += xv;
-                s2 = __builtin_elementwise_fma(xv, xv, s2);
+                s1[0] += x0; s2[0] = fmaf(x0, x0, s2[0]);
+                s1[1] += x1; s2[1] = fmaf(x1, x1, s2[1]);
             }
 #pragma unroll
             for (int i = 0; i < MT; ++i) {

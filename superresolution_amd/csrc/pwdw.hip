@@ -7,7 +7,7 @@
 //   * its 16 weight rows sit in LDS in MFMA operand form (one float per lane and k-step) for the
 //     whole launch;
 //   * per row, the K input channels of the strip (plus four pixels either side) stream through a
-//     5-deep LDS ring in chunks of 24 channels, filled by LDS-DMA only; the wave multiplies its
+//     4- or 5-deep LDS ring in chunks of 48 or 24 channels, filled by LDS-DMA only; the wave multiplies its
 //     slab into 4 accumulator tiles of 16 pixels (v_mfma_f32_16x16x4_f32, exact fp32);
 //   * the two halo columns (one pixel left and right of the strip) are plain dot products on the
 //     vector ALU, taken from the same ring -- a fifth MFMA tile for two columns would cost 25 %;
@@ -29,6 +29,7 @@
 // GATE: waves w and w + NW/2 hold channel c of the two halves; each hands the other half of its
 // finished tiles over through LDS, so both apply gelu(a) * b to half of the strip.
 #include "kernels.hpp"
+#include <type_traits>
 
 namespace rst {
 
@@ -40,16 +41,29 @@ constexpr int PW_T = 4;                  // MFMA tiles per strip row
 constexpr int PW_WT = 16 * PW_T;         // strip width
 constexpr int PW_CPR = 20;               // 16-byte pieces per channel row in LDS: 4 px halo + 64 + 4 px halo, padded
 constexpr int PW_ROWF = PW_CPR * 4;      // == 16 (mod 64): the four k-rows of an operand read hit disjoint banks
-constexpr int PW_CK = 24;                // channels per ring stage (one barrier per 24 channels: 24 MFMAs per wave)
-constexpr int PW_NINSTR = (PW_CK * PW_CPR + 63) / 64;   // wave-wide DMA instructions per chunk (8; the last one is half used)
-constexpr int PW_XCH = PW_NINSTR * 256;  // floats per ring stage (>= PW_CK * PW_ROWF)
-constexpr int PW_STAGES = 5;             // ring depth: chunks q+1 .. q+4 stream in while chunk q is multiplied
+// CK = channels per ring stage (one barrier per CK channels = CK MFMAs per wave): 48 for K = 96 (the
+// chunk boundary -- barrier, DMA issue, refilling the operand pipeline -- costs ~300 cycles), 24 for
+// K = 48, where smaller stages let more of the small blocks share a CU.
+constexpr int pw_ninstr(int ck) { return (ck * PW_CPR + 63) / 64; }   // wave-wide DMA instructions per chunk (the last may be half used)
+constexpr int pw_xch(int ck) { return pw_ninstr(ck) * 256; }          // floats per ring stage (>= ck * PW_ROWF)
+constexpr int pw_stages(int ck) { return ck >= 48 ? 4 : 5; }          // ring depth
+constexpr int pw_ck(int K) { return K >= 96 ? 48 : 24; }
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void pw_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        pw_static_for<I + 1, N>(f);
+    }
+}
 constexpr int PW_NSG = PW_ROWF / 16;     // groups of 16 ring columns for the statistics (5)
 
 // QLDS: the running sum of the row below (see header) lives in LDS instead of registers.
-template <int KS, int NW, bool GATE, bool QLDS>
-__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(GATE ? 2 : 3, GATE ? 2 : 3)))
+// PIPE: the depthwise phase of row r-1 is interleaved with the MFMAs of row r (see epi_piece).
+template <int KS, int NW, bool GATE, bool QLDS, bool PIPE, int PW_CK>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu((GATE || KS > 12) ? 2 : 3, (GATE || KS > 12) ? 2 : 3)))
 pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
+    constexpr int PW_NINSTR = pw_ninstr(PW_CK), PW_XCH = pw_xch(PW_CK), PW_STAGES = pw_stages(PW_CK);
     constexpr int T = PW_T, WT = PW_WT, ROWF = PW_ROWF, XCH = PW_XCH;
     constexpr int P = (PW_NINSTR + NW - 1) / NW;     // DMA instructions per wave per chunk (surplus ones land in a dummy area)
     constexpr int CKS = PW_CK / 4;                   // k-steps per chunk
@@ -60,9 +74,9 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
     constexpr int PAIRS = NW / 2, HT = T / 2;
     extern __shared__ __attribute__((aligned(16))) float pw_smem[];
     float* ring = pw_smem;                               // PW_STAGES stages + 256 floats for surplus DMA pieces
-    float* statm = ring + PW_STAGES * XCH + 256;                 // [80] minus mean (or 0) per ring column
-    float* statr = statm + ROWF;                         // [80] 1/sqrt(var + eps)
-    float* xch = statr + ROWF;                           // GATE: [PAIRS][2][HT][64] float4 hand-over area
+    float* statm = ring + PW_STAGES * XCH + 256;                 // [2][80] minus mean (or 0) per ring column, by row parity
+    float* statr = statm + 2 * ROWF;                     // [2][80] 1/sqrt(var + eps)
+    float* xch = statr + 2 * ROWF;                       // GATE: [PAIRS][2][HT][64] float4 hand-over area
     float* qbuf = xch + (GATE ? PAIRS * 2 * HT * 256 : 0);   // QLDS: [NW][T][64] float4
     float* wlds = qbuf + (QLDS ? NW * T * 256 : 0);      // [NW][KS][64] weights as MFMA B operand
 
@@ -182,6 +196,94 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
     for (int i = 0; i < PW_STAGES - 1; ++i) issue(i < nq ? i : nq - 1, i);
     int qc = 0, stage_c = 0;                             // chunk being consumed and its stage
 
+    // ---- the depthwise phase of a finished row, cut into pieces ----
+    // tp[] = the raw 1x1 accumulators of row `prow`, hlp/hrp its raw halo shares; their LayerNorm
+    // constants sit in stat buffer prow & 1.  With PIPE the pieces are placed between the MFMAs of the
+    // NEXT row (one piece after a k-step, spread over the row), so that the vector ALU works in the
+    // shadow of the matrix pipe; without PIPE they run back to back right after the row.
+    f32x4 tp[T];
+    float hlp = 0.f, hrp = 0.f, hlf = 0.f, hrf = 0.f;
+    int prow = -1;
+    auto piece_halo = [&]() {
+        hlp += __shfl_xor(hlp, 16); hrp += __shfl_xor(hrp, 16);
+        hlp += __shfl_xor(hlp, 32); hrp += __shfl_xor(hrp, 32);
+        const float* sm = statm + (prow & 1) * ROWF;
+        const float* sr = statr + (prow & 1) * ROWF;
+        float tl = 0.f, rl = 1.f, tr = 0.f, rr = 1.f;
+        if (a.ln_mode != 0) { tl = sm[3]; rl = sr[3]; tr = sm[4 + WT]; rr = sr[4 + WT]; }
+        hlf = in_l ? fmaf(rl, fmaf(tl, lns, hlp), lnc) : 0.f;
+        hrf = in_r ? fmaf(rr, fmaf(tr, lns, hrp), lnc) : 0.f;
+    };
+    // 1x1 output of a tile: LayerNorm constants and bias, then zero outside the image
+    auto piece_finish = [&](int j) {
+        const int px = px0 + 16 * j + 4 * kk;
+        f32x4 tco = {0.f, 0.f, 0.f, 0.f}, rstd = {1.f, 1.f, 1.f, 1.f};
+        if (a.ln_mode != 0) {
+            tco = *reinterpret_cast<const f32x4*>(&statm[(prow & 1) * ROWF + 4 + 16 * j + 4 * kk]);
+            rstd = *reinterpret_cast<const f32x4*>(&statr[(prow & 1) * ROWF + 4 + 16 * j + 4 * kk]);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float v = fmaf(rstd[q], fmaf(tco[q], lns, tp[j][q]), lnc);
+            tp[j][q] = px < W ? v : 0.f;              // W % 4 == 0: the four pixels are inside or outside together
+        }
+    };
+    // depthwise 3x3 of tile j: row prow's share of output rows prow-1 (now complete), prow and prow+1
+    auto piece_dw = [&](int j) {
+        const bool emit = prow - 1 >= R0 && prow - 1 < R1;
+        // e[0..5]: the pixel before the tile's four, the four, and the one after
+        float e[6];
+        {
+            const float same = __int_as_float(__builtin_amdgcn_ds_bpermute(nbr_prev, __float_as_int(tp[j][3])));
+            const float other = j > 0 ? __int_as_float(__builtin_amdgcn_ds_bpermute(nbr_prev, __float_as_int(tp[j > 0 ? j - 1 : 0][3]))) : hlf;
+            e[0] = kk == 0 ? other : same;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) e[1 + q] = tp[j][q];
+        {
+            const float same = __int_as_float(__builtin_amdgcn_ds_bpermute(nbr_next, __float_as_int(tp[j][0])));
+            const float other = j + 1 < T ? __int_as_float(__builtin_amdgcn_ds_bpermute(nbr_next, __float_as_int(tp[j + 1 < T ? j + 1 : j][0]))) : hrf;
+            e[5] = kk == 3 ? other : same;
+        }
+        f32x4 qold;
+        if constexpr (QLDS) qold = myq[j * 64]; else qold = Qst[j];
+        f32x4 done, pn, qn;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            done[q] = fmaf(wv[8], e[q + 2], fmaf(wv[7], e[q + 1], fmaf(wv[6], e[q], Pst[j][q])));
+            pn[q] = fmaf(wv[5], e[q + 2], fmaf(wv[4], e[q + 1], fmaf(wv[3], e[q], qold[q])));
+            qn[q] = fmaf(wv[2], e[q + 2], fmaf(wv[1], e[q + 1], fmaf(wv[0], e[q], bq)));
+        }
+        Pst[j] = pn;
+        if constexpr (QLDS) myq[j * 64] = qn; else Qst[j] = qn;
+        if (emit) {
+            if constexpr (GATE) stash(done, j);
+            else store_tile(done, prow - 1, j);
+        }
+    };
+    // order: a tile is finished before the depthwise of its left neighbour needs its first pixel
+    auto run_piece = [&](int p) {
+        switch (p) {
+            case 0: piece_halo(); piece_finish(0); break;
+            case 1: piece_finish(1); break;
+            case 2: piece_dw(0); break;
+            case 3: piece_finish(2); break;
+            case 4: piece_dw(1); break;
+            case 5: piece_finish(3); break;
+            case 6: piece_dw(2); break;
+            case 7: piece_dw(3); break;
+            default: break;
+        }
+    };
+    constexpr int NPIECE = 8;
+    // k-step `idx` of a row (0 .. KS-1) carries piece p when idx == p * KS / NPIECE
+    auto epi_piece = [&](int idx) {
+        if (prow < 0) return;
+#pragma unroll
+        for (int p = 0; p < NPIECE; ++p)
+            if (idx == p * KS / NPIECE) run_piece(p);
+    };
+
     for (int r = ra; r <= rb; ++r) {
 #pragma unroll
         for (int j = 0; j < T; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -196,11 +298,13 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
             // for everyone; the barrier also frees the stage that is refilled next
             // (lgkmcnt: LDS writes of the previous phase -- the GATE hand-over -- are visible after the barrier)
             // (PW_STAGES - 2) newer chunks of P pieces each may still be in flight
-            static_assert(PW_STAGES == 5, "wait counts below are for three newer chunks");
-            if constexpr (P == 1) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else if constexpr (P == 2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            static_assert(P == 1 || P == 2 || P == 3, "wait count");
+            constexpr int NEWER = (PW_STAGES - 2) * P;      // pieces of the (PW_STAGES - 2) newer chunks
+            if constexpr (NEWER == 3) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else if constexpr (NEWER == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else if constexpr (NEWER == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else if constexpr (NEWER == 9) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else if constexpr (NEWER == 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else static_assert(NEWER == 3, "add the wait count for this configuration");
             {
                 const int qn = qc + PW_STAGES - 1 < nq ? qc + PW_STAGES - 1 : nq - 1;   // past the end: keeps the per-wave count fixed, rewrites identical data
                 issue(qn, qn % PW_STAGES);
@@ -220,37 +324,37 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
             const unsigned wb = (unsigned)(uintptr_t)(pw_lptr)(mywl + c * CKS * 64);
             pw_f32x2 x01[3], x23[3], xh[3];
             float wq[3];
-#define PW_FETCH(S)                                                                                             \
-            do {                                                                                                \
-                constexpr int SET = (S) % 3;                                                                    \
-                const unsigned tbs = tb + (S) * 4 * ROWF * 4, hbs = hb + (S) * 4 * ROWF * 4;                   \
-                asm volatile("ds_read2_b32 %0, %1 offset0:4 offset1:20" : "=v"(x01[SET]) : "v"(tbs));          \
-                asm volatile("ds_read2_b32 %0, %1 offset0:36 offset1:52" : "=v"(x23[SET]) : "v"(tbs));         \
-                asm volatile("ds_read2_b32 %0, %1 offset0:3 offset1:68" : "=v"(xh[SET]) : "v"(hbs));           \
-                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(wq[SET]) : "v"(wb), "n"((S) * 256));         \
-            } while (0)
-#define PW_USE(S, NEWER)                                                                                        \
-            do {                                                                                                \
-                constexpr int SET = (S) % 3;                                                                    \
-                asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(x01[SET]), "+v"(x23[SET]), "+v"(xh[SET]), "+v"(wq[SET]) : "n"(NEWER)); \
-                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x01[SET][0], wq[SET], acc[0], 0, 0, 0);           \
-                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x01[SET][1], wq[SET], acc[1], 0, 0, 0);           \
-                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(x23[SET][0], wq[SET], acc[2], 0, 0, 0);           \
-                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(x23[SET][1], wq[SET], acc[3], 0, 0, 0);           \
-                hl = fmaf(wq[SET], xh[SET][0], hl);                                                             \
-                hr = fmaf(wq[SET], xh[SET][1], hr);                                                             \
-            } while (0)
-            static_assert(CKS == 6 && T == 4 && WT == 64, "the hand-scheduled k loop is written for 6 steps of 4 tiles");
-            PW_FETCH(0);
-            PW_FETCH(1);
-            PW_FETCH(2); PW_USE(0, 8);
-            PW_FETCH(3); PW_USE(1, 8);
-            PW_FETCH(4); PW_USE(2, 8);
-            PW_FETCH(5); PW_USE(3, 8);
-            PW_USE(4, 4);
-            PW_USE(5, 0);
-#undef PW_FETCH
-#undef PW_USE
+            auto fetch = [&](auto Sc) {
+                constexpr int S = decltype(Sc)::value, SET = S % 3;
+                const unsigned tbs = tb + S * 4 * ROWF * 4, hbs = hb + S * 4 * ROWF * 4, wbs = wb;
+                // (asm operands do not capture implicitly: bind the captured registers to locals first)
+                pw_f32x2 &r01 = x01[SET], &r23 = x23[SET], &rh = xh[SET];
+                float& rw = wq[SET];
+                asm volatile("ds_read2_b32 %0, %1 offset0:4 offset1:20" : "=v"(r01) : "v"(tbs));
+                asm volatile("ds_read2_b32 %0, %1 offset0:36 offset1:52" : "=v"(r23) : "v"(tbs));
+                asm volatile("ds_read2_b32 %0, %1 offset0:3 offset1:68" : "=v"(rh) : "v"(hbs));
+                asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(rw) : "v"(wbs), "n"(S * 256));
+            };
+            static_assert(T == 4 && WT == 64 && CKS >= 3, "the hand-scheduled k loop is written for 4 tiles");
+            fetch(std::integral_constant<int, 0>{});
+            fetch(std::integral_constant<int, 1>{});
+            pw_static_for<0, CKS>([&](auto Sc) {
+                constexpr int S = decltype(Sc)::value, SET = S % 3;
+                if constexpr (S + 2 < CKS) fetch(std::integral_constant<int, S + 2>{});
+                // reads of the (up to two) later steps may still be outstanding: 4 instructions each
+                pw_f32x2 &r01 = x01[SET], &r23 = x23[SET], &rh = xh[SET];
+                float& rw = wq[SET];
+                if constexpr (S + 2 < CKS) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(r01), "+v"(r23), "+v"(rh), "+v"(rw));
+                else if constexpr (S + 1 < CKS) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(r01), "+v"(r23), "+v"(rh), "+v"(rw));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r01), "+v"(r23), "+v"(rh), "+v"(rw));
+                acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x01[SET][0], wq[SET], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x01[SET][1], wq[SET], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(x23[SET][0], wq[SET], acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(x23[SET][1], wq[SET], acc[3], 0, 0, 0);
+                hl = fmaf(wq[SET], xh[SET][0], hl);
+                hr = fmaf(wq[SET], xh[SET][1], hr);
+                if constexpr (PIPE) epi_piece(c * CKS + S);
+            });
             if (a.ln_mode != 0) {
 #pragma unroll
                 for (int jj = 0; jj < NTW; ++jj) {
@@ -268,7 +372,7 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
             stage_c = stage_c == PW_STAGES - 1 ? 0 : stage_c + 1;
         }
 
-        // ---- per-pixel LayerNorm constants of the row, shared through LDS ----
+        // ---- per-pixel LayerNorm constants of the row, shared through LDS (buffer r & 1) ----
         if (a.ln_mode != 0) {
 #pragma unroll
             for (int jj = 0; jj < NTW; ++jj) {
@@ -280,74 +384,30 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
                     const float mu = s1 * (1.0f / (4 * KS));
                     const float var = fmaxf(s2 * (1.0f / (4 * KS)) - mu * mu, 0.f);
                     if (kk == 0) {
-                        statm[16 * sg + lm] = a.ln_mode == 1 ? -mu : 0.f;
-                        statr[16 * sg + lm] = 1.0f / sqrtf(var + 1e-5f);
+                        statm[(r & 1) * ROWF + 16 * sg + lm] = a.ln_mode == 1 ? -mu : 0.f;
+                        statr[(r & 1) * ROWF + 16 * sg + lm] = 1.0f / sqrtf(var + 1e-5f);
                     }
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
-        // halo columns: add the four k shares, then constants and mask like every other pixel
-        hl += __shfl_xor(hl, 16); hr += __shfl_xor(hr, 16);
-        hl += __shfl_xor(hl, 32); hr += __shfl_xor(hr, 32);
-        {
-            float tl = 0.f, rl = 1.f, tr = 0.f, rr = 1.f;
-            if (a.ln_mode != 0) { tl = statm[3]; rl = statr[3]; tr = statm[4 + WT]; rr = statr[4 + WT]; }
-            hl = in_l ? fmaf(rl, fmaf(tl, lns, hl), lnc) : 0.f;
-            hr = in_r ? fmaf(rr, fmaf(tr, lns, hr), lnc) : 0.f;
+        // hand the row over to the depthwise phase
+#pragma unroll
+        for (int j = 0; j < T; ++j) tp[j] = acc[j];
+        hlp = hl; hrp = hr;
+        prow = r;
+        if constexpr (!PIPE) {
+#pragma unroll
+            for (int p = 0; p < NPIECE; ++p) run_piece(p);
+            if constexpr (GATE) { if (prow - 1 >= R0 && prow - 1 < R1) pend_row = prow - 1; }
         }
-        // 1x1 output of a tile: LayerNorm constants and bias, then zero outside the image
-        auto finish_tile = [&](int j) {
-            const int px = px0 + 16 * j + 4 * kk;
-            f32x4 tco = {0.f, 0.f, 0.f, 0.f}, rstd = {1.f, 1.f, 1.f, 1.f};
-            if (a.ln_mode != 0) {
-                tco = *reinterpret_cast<const f32x4*>(&statm[4 + 16 * j + 4 * kk]);
-                rstd = *reinterpret_cast<const f32x4*>(&statr[4 + 16 * j + 4 * kk]);
-            }
+    }
+    if constexpr (PIPE) {
+        // the last row's depthwise phase has no next row to hide behind
+        if (prow >= 0) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float v = fmaf(rstd[q], fmaf(tco[q], lns, acc[j][q]), lnc);
-                acc[j][q] = px < W ? v : 0.f;             // W % 4 == 0: the four pixels are inside or outside together
-            }
-        };
-        finish_tile(0);
-
-        // ---- depthwise 3x3: this row's share of output rows r-1 (now complete), r and r+1 ----
-        const bool emit = r - 1 >= R0 && r - 1 < R1;
-#pragma unroll
-        for (int j = 0; j < T; ++j) {
-            if (j + 1 < T) finish_tile(j + 1);
-            // e[0..5]: the pixel before the tile's four, the four, and the one after
-            float e[6];
-            {
-                const float same = __int_as_float(__builtin_amdgcn_ds_bpermute(nbr_prev, __float_as_int(acc[j][3])));
-                const float other = j > 0 ? __int_as_float(__builtin_amdgcn_ds_bpermute(nbr_prev, __float_as_int(acc[j > 0 ? j - 1 : 0][3]))) : hl;
-                e[0] = kk == 0 ? other : same;
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) e[1 + q] = acc[j][q];
-            {
-                const float same = __int_as_float(__builtin_amdgcn_ds_bpermute(nbr_next, __float_as_int(acc[j][0])));
-                const float other = j + 1 < T ? __int_as_float(__builtin_amdgcn_ds_bpermute(nbr_next, __float_as_int(acc[j + 1 < T ? j + 1 : j][0]))) : hr;
-                e[5] = kk == 3 ? other : same;
-            }
-            f32x4 qold;
-            if constexpr (QLDS) qold = myq[j * 64]; else qold = Qst[j];
-            f32x4 done, pn, qn;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                done[q] = fmaf(wv[8], e[q + 2], fmaf(wv[7], e[q + 1], fmaf(wv[6], e[q], Pst[j][q])));
-                pn[q] = fmaf(wv[5], e[q + 2], fmaf(wv[4], e[q + 1], fmaf(wv[3], e[q], qold[q])));
-                qn[q] = fmaf(wv[2], e[q + 2], fmaf(wv[1], e[q + 1], fmaf(wv[0], e[q], bq)));
-            }
-            Pst[j] = pn;
-            if constexpr (QLDS) myq[j * 64] = qn; else Qst[j] = qn;
-            if (emit) {
-                if constexpr (GATE) stash(done, j);
-                else store_tile(done, r - 1, j);
-            }
+            for (int p = 0; p < NPIECE; ++p) run_piece(p);
         }
-        if constexpr (GATE) { if (emit) pend_row = r - 1; }
     }
 
     // all DMA (including the surplus re-issues) must have landed before the block's LDS is released
@@ -399,11 +459,10 @@ static PwPlan pwdw_plan(const PwDw& a) {
 
 bool pwdw_supported(const PwDw& a) { return pwdw_plan(a).ok; }
 
-// Measured on MI355X (16 x C x 256 x 256): at 48 input channels the fused kernel beats the
-// product + depthwise pair (about 400 vs 530 us for qkv, 390 vs 420 us gated); at 96 channels the
-// two are level (1230 vs 1210 us, 970 vs 980 us): the streaming of the input rows, the MFMA phase
-// and the depthwise phase still run back to back instead of overlapping, so it stays opt-in there.
-bool pwdw_profitable(const PwDw& a) { return pwdw_plan(a).ok && a.K == 48; }
+// Measured on MI355X (16 x C x 256 x 256, one box, fused vs the product + depthwise pair): 48 channels
+// 405 vs 530 us (qkv) and 390 vs 420 us (gated); 96 channels 1130 vs 1210 us and 935 vs 980 us; at
+// 128 x 128 and 96 channels 320 vs 340 us and 245 vs 270 us.  Fused wherever it is supported.
+bool pwdw_profitable(const PwDw& a) { return pwdw_plan(a).ok; }
 
 int pwdw_launch(const PwDw& a, hipStream_t stream) {
     PwPlan p = pwdw_plan(a);
@@ -415,13 +474,13 @@ int pwdw_launch(const PwDw& a, hipStream_t stream) {
     RST_HIP(hipGetDevice(&dev));
     RST_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const void* kern = nullptr;
-#define PW_KS(NWV, GT) do { if (p.ks == 12) kern = reinterpret_cast<const void*>(&pwdw_kernel<12, NWV, GT, false>); \
-                            else kern = reinterpret_cast<const void*>(&pwdw_kernel<24, NWV, GT, false>); } while (0)
-    if (a.gate) PW_KS(8, true);
-    else if (p.nw == 6) PW_KS(6, false);
-    else PW_KS(3, false);
+#define PW_KS(NWV, GT, PP) do { if (p.ks == 12) kern = reinterpret_cast<const void*>(&pwdw_kernel<12, NWV, GT, false, PP, pw_ck(48)>); \
+                                else kern = reinterpret_cast<const void*>(&pwdw_kernel<24, NWV, GT, false, PP, pw_ck(96)>); } while (0)
+    if (a.gate) PW_KS(8, true, false);
+    else if (p.nw == 6) PW_KS(6, false, true);
+    else PW_KS(3, false, true);
 #undef PW_KS
-    const size_t lds = sizeof(float) * (size_t)(PW_STAGES * PW_XCH + 256 + 2 * PW_ROWF +
+    const size_t lds = sizeof(float) * (size_t)(pw_stages(pw_ck(a.K)) * pw_xch(pw_ck(a.K)) + 256 + 4 * PW_ROWF +
                                                 (a.gate ? (p.nw / 2) * 2 * (PW_T / 2) * 256 : 0) + p.nw * p.ks * 64 + 256);
     if (lds > 64 * 1024) RST_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int per_cu = 1;
