@@ -174,19 +174,20 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
         if (mine) hold[j % HN] = v;
         else myx[(j % HN) * 64] = v;
     };
-    auto finalize = [&](int row) {                      // GATE: gelu(first half) * second half on my tiles
+    auto finalize_tile = [&](int row, int jh) {         // GATE: gelu(first half) * second half on one of my tiles
+        const f32x4 other = ptx[jh * 64];
+        f32x4 o;
 #pragma unroll
-        for (int jh = 0; jh < HN; ++jh) {
-            const f32x4 other = ptx[jh * 64];
-            f32x4 o;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float x1 = half == 0 ? hold[jh][q] : other[q];
-                const float x2 = half == 0 ? other[q] : hold[jh][q];
-                o[q] = gelu_erf(x1) * x2;
-            }
-            store_tile(o, row, half * HT + jh);
+        for (int q = 0; q < 4; ++q) {
+            const float x1 = half == 0 ? hold[jh][q] : other[q];
+            const float x2 = half == 0 ? other[q] : hold[jh][q];
+            o[q] = gelu_erf(x1) * x2;
         }
+        store_tile(o, row, half * HT + jh);
+    };
+    auto finalize = [&](int row) {
+#pragma unroll
+        for (int jh = 0; jh < HN; ++jh) finalize_tile(row, jh);
     };
     // byte addresses (for ds_bpermute) of the lanes that hold the previous / next 4 pixels of the channel
     const int nbr_next = ((lane + 16) & 63) * 4, nbr_prev = ((lane + 48) & 63) * 4;
@@ -276,12 +277,32 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
         }
     };
     constexpr int NPIECE = 8;
-    // k-step `idx` of a row (0 .. KS-1) carries piece p when idx == p * KS / NPIECE
+    // k-step `idx` of a row (0 .. KS-1) carries piece p when idx == p * KS / NPIECE.
+    // GATE: the hand-over area is read by the finalize pieces (previous output row) and written by
+    // the depthwise pieces; a chunk barrier has to lie between the two in both directions, so the
+    // finalize pieces and the tile finishing take the first half of the row's k-steps and the four
+    // depthwise pieces the second half (every row has an even number of chunks >= 2).
     auto epi_piece = [&](int idx) {
-        if (prow < 0) return;
+        if constexpr (GATE) {
+            static_assert(!PIPE || (NC % 2 == 0 && HN == 2), "the split of the pieces assumes two halves of whole chunks");
+            constexpr int HALF = KS / 2;
+            // (explicit constants: the register arrays must be indexed at compile time)
+            if (idx == 0 * HALF / 6) { if (pend_row >= 0) finalize_tile(pend_row, 0); }
+            else if (idx == 1 * HALF / 6) { if (pend_row >= 0) finalize_tile(pend_row, 1); }
+            else if (idx == 2 * HALF / 6) { if (prow >= 0) { piece_halo(); piece_finish(0); } }
+            else if (idx == 3 * HALF / 6) { if (prow >= 0) piece_finish(1); }
+            else if (idx == 4 * HALF / 6) { if (prow >= 0) piece_finish(2); }
+            else if (idx == 5 * HALF / 6) { if (prow >= 0) piece_finish(3); }
+            else if (idx == HALF + 0 * HALF / 4) { if (prow >= 0) piece_dw(0); }
+            else if (idx == HALF + 1 * HALF / 4) { if (prow >= 0) piece_dw(1); }
+            else if (idx == HALF + 2 * HALF / 4) { if (prow >= 0) piece_dw(2); }
+            else if (idx == HALF + 3 * HALF / 4) { if (prow >= 0) piece_dw(3); }
+        } else {
+            if (prow < 0) return;
 #pragma unroll
-        for (int p = 0; p < NPIECE; ++p)
-            if (idx == p * KS / NPIECE) run_piece(p);
+            for (int p = 0; p < NPIECE; ++p)
+                if (idx == p * KS / NPIECE) run_piece(p);
+        }
     };
 
     for (int r = ra; r <= rb; ++r) {
@@ -309,7 +330,7 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
                 const int qn = qc + PW_STAGES - 1 < nq ? qc + PW_STAGES - 1 : nq - 1;   // past the end: keeps the per-wave count fixed, rewrites identical data
                 issue(qn, qn % PW_STAGES);
             }
-            if constexpr (GATE) {
+            if constexpr (GATE && !PIPE) {
                 if (c == 0 && pend_row >= 0) { finalize(pend_row); pend_row = -1; }
             }
             const float* Xc = ring + stage_c * XCH + kk * ROWF;
@@ -391,6 +412,10 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
             }
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
+        if constexpr (GATE && PIPE) {
+            // the pieces that rode on this row finished output row prow-1 (handed over, final after the next barrier)
+            pend_row = (prow >= 0 && prow - 1 >= R0 && prow - 1 < R1) ? prow - 1 : -1;
+        }
         // hand the row over to the depthwise phase
 #pragma unroll
         for (int j = 0; j < T; ++j) tp[j] = acc[j];
@@ -404,9 +429,16 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
     }
     if constexpr (PIPE) {
         // the last row's depthwise phase has no next row to hide behind
+        if constexpr (GATE) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (pend_row >= 0) finalize(pend_row);
+            pend_row = -1;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // partners are done reading before the next hand-over
+        }
         if (prow >= 0) {
 #pragma unroll
             for (int p = 0; p < NPIECE; ++p) run_piece(p);
+            if constexpr (GATE) { if (prow - 1 >= R0 && prow - 1 < R1) pend_row = prow - 1; }
         }
     }
 
@@ -476,7 +508,7 @@ int pwdw_launch(const PwDw& a, hipStream_t stream) {
     const void* kern = nullptr;
 #define PW_KS(NWV, GT, PP) do { if (p.ks == 12) kern = reinterpret_cast<const void*>(&pwdw_kernel<12, NWV, GT, false, PP, pw_ck(48)>); \
                                 else kern = reinterpret_cast<const void*>(&pwdw_kernel<24, NWV, GT, false, PP, pw_ck(96)>); } while (0)
-    if (a.gate) PW_KS(8, true, false);
+    if (a.gate) PW_KS(8, true, true);
     else if (p.nw == 6) PW_KS(6, false, true);
     else PW_KS(3, false, true);
 #undef PW_KS
