@@ -136,7 +136,7 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
     }
     // chunk q of the block's stream: row ra + q / NC, channels (q % NC) * 48 ..; lands in ring stage q % PW_STAGES
     const int nq = (rb - ra + 1) * NC;
-    auto issue = [&](int q, int stage) {
+    auto issue = [&](int q, int stage) __attribute__((always_inline)) {
         const int row = ra + q / NC, c = q % NC;
         const char* src = Xb + 4 * ((int64_t)c * PW_CK * HW + (int64_t)row * W);
 #pragma unroll
@@ -159,33 +159,35 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
         if constexpr (QLDS) myq[j * 64] = bq4; else Qst[j] = bq4;
     }
     constexpr int HN = GATE ? HT : 1;
-    f32x4 hold[HN];
+    f32x4 hold0 = {0.f, 0.f, 0.f, 0.f}, hold1 = {0.f, 0.f, 0.f, 0.f};     // my half of the strip (HN <= 2 tiles), named so they stay in registers
+    static_assert(HN <= 2, "two hand-over tiles per wave");
     int pend_row = -1;
     f32x4* myx = reinterpret_cast<f32x4*>(xch) + (GATE ? ((wave % PAIRS) * 2 + half) * HT * 64 + lane : 0);        // handed over by this wave
     const f32x4* ptx = reinterpret_cast<const f32x4*>(xch) + (GATE ? ((wave % PAIRS) * 2 + (1 - half)) * HT * 64 + lane : 0);
 
     // finished output tile `j` of row `row`: 4 consecutive pixels of one channel per lane
-    auto store_tile = [&](const f32x4& v, int row, int j) {
+    auto store_tile = [&](const f32x4& v, int row, int j) __attribute__((always_inline)) {
         const int px = px0 + 16 * j + 4 * kk;
         if (chok && px < W) *reinterpret_cast<f32x4*>(Yb + (int64_t)row * W + px) = v;
     };
-    auto stash = [&](const f32x4& v, int j) {           // GATE: keep my half of the strip, hand the other half over
+    auto stash = [&](const f32x4& v, int j) __attribute__((always_inline)) {           // GATE: keep my half of the strip, hand the other half over
         const bool mine = (j < HT) == (half == 0);
-        if (mine) hold[j % HN] = v;
+        if (mine) { if (j % HN == 0) hold0 = v; else hold1 = v; }
         else myx[(j % HN) * 64] = v;
     };
-    auto finalize_tile = [&](int row, int jh) {         // GATE: gelu(first half) * second half on one of my tiles
+    auto finalize_tile = [&](int row, int jh) __attribute__((always_inline)) {         // GATE: gelu(first half) * second half on one of my tiles
         const f32x4 other = ptx[jh * 64];
         f32x4 o;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float x1 = half == 0 ? hold[jh][q] : other[q];
-            const float x2 = half == 0 ? other[q] : hold[jh][q];
+            const float hv = jh == 0 ? hold0[q] : hold1[q];
+            const float x1 = half == 0 ? hv : other[q];
+            const float x2 = half == 0 ? other[q] : hv;
             o[q] = gelu_erf(x1) * x2;
         }
         store_tile(o, row, half * HT + jh);
     };
-    auto finalize = [&](int row) {
+    auto finalize = [&](int row) __attribute__((always_inline)) {
 #pragma unroll
         for (int jh = 0; jh < HN; ++jh) finalize_tile(row, jh);
     };
@@ -205,7 +207,7 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
     f32x4 tp[T];
     float hlp = 0.f, hrp = 0.f, hlf = 0.f, hrf = 0.f;
     int prow = -1;
-    auto piece_halo = [&]() {
+    auto piece_halo = [&]() __attribute__((always_inline)) {
         hlp += __shfl_xor(hlp, 16); hrp += __shfl_xor(hrp, 16);
         hlp += __shfl_xor(hlp, 32); hrp += __shfl_xor(hrp, 32);
         const float* sm = statm + (prow & 1) * ROWF;
@@ -216,7 +218,7 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
         hrf = in_r ? fmaf(rr, fmaf(tr, lns, hrp), lnc) : 0.f;
     };
     // 1x1 output of a tile: LayerNorm constants and bias, then zero outside the image
-    auto piece_finish = [&](int j) {
+    auto piece_finish = [&](int j) __attribute__((always_inline)) {
         const int px = px0 + 16 * j + 4 * kk;
         f32x4 tco = {0.f, 0.f, 0.f, 0.f}, rstd = {1.f, 1.f, 1.f, 1.f};
         if (a.ln_mode != 0) {
@@ -229,11 +231,11 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
             tp[j][q] = px < W ? v : 0.f;              // W % 4 == 0: the four pixels are inside or outside together
         }
     };
-    // depthwise 3x3 of tile j: row prow's share of output rows prow-1 (now complete), prow and prow+1
-    auto piece_dw = [&](int j) {
-        const bool emit = prow - 1 >= R0 && prow - 1 < R1;
-        // e[0..5]: the pixel before the tile's four, the four, and the one after
-        float e[6];
+    // depthwise 3x3 of tile j: row prow's share of output rows prow-1 (now complete), prow and prow+1,
+    // in four sub-pieces small enough to hide between two k-steps: (a) the six pixels e[0..5] (the one
+    // before the tile's four, the four, the one after), (b) the finished row, (c), (d) the two running sums
+    float e[6];
+    auto dw_a = [&](int j) __attribute__((always_inline)) {
         {
             const float same = __int_as_float(__builtin_amdgcn_ds_bpermute(nbr_prev, __float_as_int(tp[j][3])));
             const float other = j > 0 ? __int_as_float(__builtin_amdgcn_ds_bpermute(nbr_prev, __float_as_int(tp[j > 0 ? j - 1 : 0][3]))) : hlf;
@@ -246,24 +248,31 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
             const float other = j + 1 < T ? __int_as_float(__builtin_amdgcn_ds_bpermute(nbr_next, __float_as_int(tp[j + 1 < T ? j + 1 : j][0]))) : hrf;
             e[5] = kk == 3 ? other : same;
         }
-        f32x4 qold;
-        if constexpr (QLDS) qold = myq[j * 64]; else qold = Qst[j];
-        f32x4 done, pn, qn;
+    };
+    auto dw_b = [&](int j) __attribute__((always_inline)) {
+        f32x4 done;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            done[q] = fmaf(wv[8], e[q + 2], fmaf(wv[7], e[q + 1], fmaf(wv[6], e[q], Pst[j][q])));
-            pn[q] = fmaf(wv[5], e[q + 2], fmaf(wv[4], e[q + 1], fmaf(wv[3], e[q], qold[q])));
-            qn[q] = fmaf(wv[2], e[q + 2], fmaf(wv[1], e[q + 1], fmaf(wv[0], e[q], bq)));
-        }
-        Pst[j] = pn;
-        if constexpr (QLDS) myq[j * 64] = qn; else Qst[j] = qn;
-        if (emit) {
+        for (int q = 0; q < 4; ++q) done[q] = fmaf(wv[8], e[q + 2], fmaf(wv[7], e[q + 1], fmaf(wv[6], e[q], Pst[j][q])));
+        if (prow - 1 >= R0 && prow - 1 < R1) {
             if constexpr (GATE) stash(done, j);
             else store_tile(done, prow - 1, j);
         }
     };
+    auto dw_c = [&](int j) __attribute__((always_inline)) {
+        f32x4 qold;
+        if constexpr (QLDS) qold = myq[j * 64]; else qold = Qst[j];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Pst[j][q] = fmaf(wv[5], e[q + 2], fmaf(wv[4], e[q + 1], fmaf(wv[3], e[q], qold[q])));
+    };
+    auto dw_d = [&](int j) __attribute__((always_inline)) {
+        f32x4 qn;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) qn[q] = fmaf(wv[2], e[q + 2], fmaf(wv[1], e[q + 1], fmaf(wv[0], e[q], bq)));
+        if constexpr (QLDS) myq[j * 64] = qn; else Qst[j] = qn;
+    };
+    auto piece_dw = [&](int j) __attribute__((always_inline)) { dw_a(j); dw_b(j); dw_c(j); dw_d(j); };
     // order: a tile is finished before the depthwise of its left neighbour needs its first pixel
-    auto run_piece = [&](int p) {
+    auto run_piece = [&](int p) __attribute__((always_inline)) {
         switch (p) {
             case 0: piece_halo(); piece_finish(0); break;
             case 1: piece_finish(1); break;
@@ -277,33 +286,49 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
         }
     };
     constexpr int NPIECE = 8;
-    // k-step `idx` of a row (0 .. KS-1) carries piece p when idx == p * KS / NPIECE.
+    // Interleaving: k-step `idx` of a row (0 .. KS-1) carries the pieces whose slot it is.  A k-step
+    // is 4 MFMAs = 128 matrix-pipe cycles, of which about 96 are free for other vector instructions,
+    // so the depthwise phase is cut into 20 pieces of 10-20 instructions and spread over the row.
     // GATE: the hand-over area is read by the finalize pieces (previous output row) and written by
     // the depthwise pieces; a chunk barrier has to lie between the two in both directions, so the
-    // finalize pieces and the tile finishing take the first half of the row's k-steps and the four
+    // finalize pieces and the tile finishing take the first half of the row's k-steps and the
     // depthwise pieces the second half (every row has an even number of chunks >= 2).
-    auto epi_piece = [&](int idx) {
+#define PW_AT(SLOT, CALL) if (idx == (SLOT)) { CALL; }
+    auto epi_piece = [&](int idx) __attribute__((always_inline)) {
         if constexpr (GATE) {
             static_assert(!PIPE || (NC % 2 == 0 && HN == 2), "the split of the pieces assumes two halves of whole chunks");
             constexpr int HALF = KS / 2;
-            // (explicit constants: the register arrays must be indexed at compile time)
-            if (idx == 0 * HALF / 6) { if (pend_row >= 0) finalize_tile(pend_row, 0); }
-            else if (idx == 1 * HALF / 6) { if (pend_row >= 0) finalize_tile(pend_row, 1); }
-            else if (idx == 2 * HALF / 6) { if (prow >= 0) { piece_halo(); piece_finish(0); } }
-            else if (idx == 3 * HALF / 6) { if (prow >= 0) piece_finish(1); }
-            else if (idx == 4 * HALF / 6) { if (prow >= 0) piece_finish(2); }
-            else if (idx == 5 * HALF / 6) { if (prow >= 0) piece_finish(3); }
-            else if (idx == HALF + 0 * HALF / 4) { if (prow >= 0) piece_dw(0); }
-            else if (idx == HALF + 1 * HALF / 4) { if (prow >= 0) piece_dw(1); }
-            else if (idx == HALF + 2 * HALF / 4) { if (prow >= 0) piece_dw(2); }
-            else if (idx == HALF + 3 * HALF / 4) { if (prow >= 0) piece_dw(3); }
+            if (pend_row >= 0) {
+                PW_AT(0 * HALF / 6, finalize_tile(pend_row, 0))
+                PW_AT(1 * HALF / 6, finalize_tile(pend_row, 1))
+            }
+            if (prow < 0) return;
+            PW_AT(2 * HALF / 6, piece_halo(); piece_finish(0))
+            PW_AT(3 * HALF / 6, piece_finish(1))
+            PW_AT(4 * HALF / 6, piece_finish(2))
+            PW_AT(5 * HALF / 6, piece_finish(3))
+            PW_AT(HALF + 0 * HALF / 16, dw_a(0))  PW_AT(HALF + 1 * HALF / 16, dw_b(0))
+            PW_AT(HALF + 2 * HALF / 16, dw_c(0))  PW_AT(HALF + 3 * HALF / 16, dw_d(0))
+            PW_AT(HALF + 4 * HALF / 16, dw_a(1))  PW_AT(HALF + 5 * HALF / 16, dw_b(1))
+            PW_AT(HALF + 6 * HALF / 16, dw_c(1))  PW_AT(HALF + 7 * HALF / 16, dw_d(1))
+            PW_AT(HALF + 8 * HALF / 16, dw_a(2))  PW_AT(HALF + 9 * HALF / 16, dw_b(2))
+            PW_AT(HALF + 10 * HALF / 16, dw_c(2)) PW_AT(HALF + 11 * HALF / 16, dw_d(2))
+            PW_AT(HALF + 12 * HALF / 16, dw_a(3)) PW_AT(HALF + 13 * HALF / 16, dw_b(3))
+            PW_AT(HALF + 14 * HALF / 16, dw_c(3)) PW_AT(HALF + 15 * HALF / 16, dw_d(3))
         } else {
             if (prow < 0) return;
-#pragma unroll
-            for (int p = 0; p < NPIECE; ++p)
-                if (idx == p * KS / NPIECE) run_piece(p);
+            constexpr int NP = 20;
+            PW_AT(0 * KS / NP, piece_halo(); piece_finish(0))
+            PW_AT(1 * KS / NP, piece_finish(1))
+            PW_AT(2 * KS / NP, dw_a(0))   PW_AT(3 * KS / NP, dw_b(0))   PW_AT(4 * KS / NP, dw_c(0))   PW_AT(5 * KS / NP, dw_d(0))
+            PW_AT(6 * KS / NP, piece_finish(2))
+            PW_AT(7 * KS / NP, dw_a(1))   PW_AT(8 * KS / NP, dw_b(1))   PW_AT(9 * KS / NP, dw_c(1))   PW_AT(10 * KS / NP, dw_d(1))
+            PW_AT(11 * KS / NP, piece_finish(3))
+            PW_AT(12 * KS / NP, dw_a(2))  PW_AT(13 * KS / NP, dw_b(2))  PW_AT(14 * KS / NP, dw_c(2))  PW_AT(15 * KS / NP, dw_d(2))
+            PW_AT(16 * KS / NP, dw_a(3))  PW_AT(17 * KS / NP, dw_b(3))  PW_AT(18 * KS / NP, dw_c(3))  PW_AT(19 * KS / NP, dw_d(3))
         }
     };
+#undef PW_AT
 
     for (int r = ra; r <= rb; ++r) {
 #pragma unroll
