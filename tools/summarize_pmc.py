@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 --pmc counter_collection.csv files of one bench.py run into the per-kernel-group
+JSON files kept under profiles/.
+
+usage: summarize_pmc.py traffic <fetch.csv> <write.csv> <out.json>
+       summarize_pmc.py mfma <counters.csv> <out.json>
+Kernel groups are the names bench.py's in-library profiler uses."""
+import collections
+import csv
+import json
+import re
+import sys
+
+LN_FOLD_PER_PASS = 88          # two LayerNorm folds per TransformerBlock, 44 blocks
+
+
+def group(name):
+    n = name.replace("void ", "")
+    m = re.match(r"rst::(\w+)<([^>]*)>", n)
+    if not m:
+        k = n.split("(")[0].replace("rst::", "")
+        return {"attn_fold_kernel": "attn_fold", "attn_softmax_kernel": "attn_softmax", "ln_fold_weights_kernel": "ln_fold",
+                "reduce_slabs_vec_kernel": "reduce_slabs", "reduce_slabs_kernel": "reduce_slabs"}.get(k, k)
+    k, args = m.group(1), [a.strip() for a in m.group(2).split(",")]
+    if k in ("gemm_nn_res_kernel", "gemm_nn_dma_kernel"):
+        return "gemm_nn_ln" if args[3] == "true" else "gemm_nn"
+    if k == "pwdw_kernel":
+        return "pwdw_gate" if args[2] == "true" else "pwdw"
+    return {"gemm_nt_kernel": "gemm_nt_splitk", "dwconv_fwd_kernel": "dwconv3x3", "dwconv_gate_fwd_kernel": "dwconv3x3_gate",
+            "pixel_shuffle2_kernel": "pixel_shuffle2+pixel_unshuffle2", "conv3x3_fewout_kernel": "conv3x3_fewout",
+            "gemm_nn_kernel": "gemm_nn"}.get(k, k)
+
+
+def load(path):
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    name = {}
+    for r in csv.DictReader(open(path)):
+        per[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
+        name[r["Dispatch_Id"]] = r["Kernel_Name"]
+    return per, name
+
+
+def passes_of(name):
+    return sum(1 for n in name.values() if "ln_fold" in n) / LN_FOLD_PER_PASS
+
+
+def traffic(fetch_csv, write_csv, out):
+    f, fn = load(fetch_csv)
+    w, wn = load(write_csv)
+    passes = passes_of(fn)
+    agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
+    for d, v in f.items():
+        agg[group(fn[d])][0] += 1
+        agg[group(fn[d])][1] += v["FETCH_SIZE"]
+    for d, v in w.items():
+        agg[group(wn[d])][2] += v["WRITE_SIZE"]
+    kernels = {}
+    for g, (n, fe, wr) in sorted(agg.items(), key=lambda kv: -(2 * kv[1][1] + kv[1][2])):
+        lp = n / passes
+        fb, wb = 2 * fe / passes * 1024, wr / passes * 1024
+        kernels[g] = {"launches_per_step": lp, "fetch_bytes_per_step": round(fb), "write_bytes_per_step": round(wb),
+                      "bytes_per_launch": round((fb + wb) / lp)}
+    json.dump({"workload": "bench.py default (Restormer dim=48 fp32 inference, 16x3x256x256)",
+               "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of bench.py --steps 1 --warmup 1; "
+                         "FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B); KB -> bytes x1024; "
+                         f"{passes:g} passes in the profiled command",
+               "config": {"batch": 16, "size": 256, "mode": "infer"},
+               "total_bytes_per_step": round(sum(k["fetch_bytes_per_step"] + k["write_bytes_per_step"] for k in kernels.values())),
+               "kernels": kernels}, open(out, "w"), indent=1)
+
+
+def mfma(counters_csv, out):
+    per, name = load(counters_csv)
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.Counter()
+    for d, v in per.items():
+        g = group(name[d])
+        cnt[g] += 1
+        for k, x in v.items():
+            agg[g][k] += x
+    kernels = {}
+    for g, v in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", 0)):
+        busy = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0)
+        if busy == 0:
+            continue
+        cyc = v["GRBM_GUI_ACTIVE"] / 8
+        kernels[g] = {"launches": cnt[g], "mfma_instructions": int(v["SQ_INSTS_MFMA"]), "mfma_busy_cycles": int(busy),
+                      "gpu_cycles": int(cyc), "mfma_utilisation": round(busy / (cyc * 1024), 4)}
+    json.dump({"workload": "bench.py --steps 1 --warmup 1 (Restormer dim=48 fp32 inference, 16x3x256x256)",
+               "method": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_WAVES GRBM_GUI_ACTIVE; "
+                         "GRBM_GUI_ACTIVE is summed over the 8 XCDs, so GPU cycles = GRBM_GUI_ACTIVE / 8; matrix-pipe "
+                         "utilisation = MFMA busy cycles / (GPU cycles x 1024 SIMDs); a v_mfma_f32_16x16x4_f32 holds the pipe 32 cycles",
+               "kernels": kernels}, open(out, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "traffic":
+        traffic(sys.argv[2], sys.argv[3], sys.argv[4])
+    else:
+        mfma(sys.argv[2], sys.argv[3])
