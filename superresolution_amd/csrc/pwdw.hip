@@ -23,6 +23,13 @@
 // LayerNorm in front of the product is folded as in gemm_nn (A = W o gamma, ln_s, ln_c): the
 // per-pixel mean / variance over the K channels are taken from the LDS ring while the chunks
 // pass (the waves share the 80 ring columns, results go through LDS once per row).
+//
+// What bounds the kernel is the issue rate of the wave's own instruction stream, not the matrix
+// pipe, LDS latency or memory (timing-only builds without the depthwise pieces, without the
+// statistics, without the DMA and without any LDS wait each take off just their own instructions'
+// worth).  Hence: no branch inside a chunk (stores are dropped by the buffer range check instead of
+// being jumped over, so that the depthwise pieces share a basic block with the MFMAs and are
+// interleaved with them), stream position kept in running scalars, LDS reads placed by hand.
 // Pixels outside the image are forced to zero AFTER the bias / LayerNorm constants, because the
 // depthwise filter pads its input -- the 1x1 output -- with zeros.
 //
@@ -71,6 +78,11 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
     static_assert(KS % CKS == 0, "K must be a multiple of the chunk depth");
     static_assert(PW_XCH >= PW_CK * PW_ROWF, "ring stage too small");
     constexpr int NTW = (PW_NSG + NW - 1) / NW;      // statistics groups per wave
+    // SFETCH: the LayerNorm statistics read their ring columns inside the hand-scheduled operand fetch (no LDS
+    // round trip of their own, no row-end barrier); it costs ~12 registers, which the 48-channel plain kernels
+    // (three waves per SIMD) do not have -- they take the statistics after each chunk instead.
+    constexpr bool SFETCH = PIPE && (GATE || KS > 12);
+    constexpr int NTF = SFETCH ? NTW : 0;            // statistics reads per fetch
     constexpr int PAIRS = NW / 2, HT = T / 2;
     extern __shared__ __attribute__((aligned(16))) float pw_smem[];
     float* ring = pw_smem;                               // PW_STAGES stages + 256 floats for surplus DMA pieces
@@ -109,6 +121,9 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
 #pragma unroll
         for (int s = 0; s < KS; ++s) mywl[s * 64] = chok ? Ar[4 * s + kk] : 0.f;
     }
+    // (0, 1) = "no LayerNorm" in both statistics buffers: final when ln_mode == 0, and a defined value for the
+    // depthwise pieces that ride on the first row of the block (they work on a row that does not exist)
+    for (int i = tid; i < 2 * ROWF; i += NW * 64) { statm[i] = 0.f; statr[i] = 1.f; }
     float wv[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) wv[t] = chok ? a.dw_w[(int64_t)wrow * 9 + t] : 0.f;
@@ -134,21 +149,37 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
             dstoff[p] = -1;
         }
     }
-    // chunk q of the block's stream: row ra + q / NC, channels (q % NC) * 48 ..; lands in ring stage q % PW_STAGES
+    // chunk q of the block's stream: row ra + q / NC, channels (q % NC) * PW_CK ..; lands in ring stage q % PW_STAGES.
+    // The stream position is kept as running scalars (source address, channel chunk, stage, chunks left):
+    // an issue is then a handful of scalar instructions -- every instruction of this loop is paid in full,
+    // the wave's own issue rate is what bounds the kernel.  Past the end the last chunk is issued again
+    // into its own stage (identical data), which keeps the per-wave count of outstanding pieces fixed.
     const int nq = (rb - ra + 1) * NC;
-    auto issue = [&](int q, int stage) __attribute__((always_inline)) {
-        const int row = ra + q / NC, c = q % NC;
-        const char* src = Xb + 4 * ((int64_t)c * PW_CK * HW + (int64_t)row * W);
+    int dsto[P];                                         // wave-uniform: LDS float offset inside a stage, < 0: surplus piece
+#pragma unroll
+    for (int p = 0; p < P; ++p) dsto[p] = __builtin_amdgcn_readfirstlane(dstoff[p]);
+    const char* isrc = Xb + 4 * (int64_t)ra * W;
+    int ic = 0, istage = 0, ileft = nq;
+    const int64_t step_c = 4 * (int64_t)PW_CK * HW, step_r = 4 * (int64_t)W - (NC - 1) * step_c;
+    auto issue = [&]() __attribute__((always_inline)) {
+        const char* src = isrc;
+        float* sbase = ring + istage * XCH;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            float* dst = dstoff[p] >= 0 ? ring + stage * XCH + dstoff[p] : ring + PW_STAGES * XCH;
+            float* dst = dsto[p] >= 0 ? sbase + dsto[p] : ring + PW_STAGES * XCH;
             __builtin_amdgcn_global_load_lds((pw_gptr)(src + srcoff[p]), (pw_lptr)dst, 16, 0, 0);
+        }
+        if (ileft > 1) {
+            const bool wrap = ic == NC - 1;
+            isrc += wrap ? step_r : step_c;
+            ic = wrap ? 0 : ic + 1;
+            istage = istage == PW_STAGES - 1 ? 0 : istage + 1;
+            --ileft;
         }
     };
 
     // accumulator layout (operands swapped: pixels are the MFMA rows): register q of tile j is pixel
     // px0 + 16*j + 4*kk + q of this lane's channel
-    float* Yb = a.Y + (int64_t)b * a.y_bs + (int64_t)(chok ? ch : 0) * HW;
     const f32x4 bq4 = {bq, bq, bq, bq};
     constexpr int QN = QLDS ? 1 : T;
     f32x4 Pst[T], Qst[QN], acc[T];
@@ -166,9 +197,25 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
     const f32x4* ptx = reinterpret_cast<const f32x4*>(xch) + (GATE ? ((wave % PAIRS) * 2 + (1 - half)) * HT * 64 + lane : 0);
 
     // finished output tile `j` of row `row`: 4 consecutive pixels of one channel per lane
-    auto store_tile = [&](const f32x4& v, int row, int j) __attribute__((always_inline)) {
+    // Stores go through a buffer descriptor over the 16 channel planes of this wave's slab: a lane that
+    // must not store (channel beyond the last, pixel beyond the row, row outside the block's range)
+    // gets an offset outside the descriptor and the hardware drops the store -- no branch, so the
+    // depthwise pieces stay in the same basic block as the MFMAs they hide behind.
+    typedef unsigned pw_u32x4 __attribute__((ext_vector_type(4)));
+    const int slab0 = __builtin_amdgcn_readfirstlane(ch - lm);
+    const int slab_n = chlim - slab0 < 0 ? 0 : (chlim - slab0 > 16 ? 16 : chlim - slab0);
+    float* slab_base = a.Y + (int64_t)b * a.y_bs + (int64_t)slab0 * HW;
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        slab_base, 0, (int)__builtin_amdgcn_readfirstlane((int)((int64_t)slab_n * HW * 4)), 0x00020000);
+    constexpr unsigned PW_NOSTORE = 0x80000000u;
+    const unsigned yoff = (unsigned)(((int64_t)lm * HW + px0 + 4 * kk) * 4);
+    auto store_tile = [&](const f32x4& v, int row, int j, bool rowok) __attribute__((always_inline)) {
         const int px = px0 + 16 * j + 4 * kk;
-        if (chok && px < W) *reinterpret_cast<f32x4*>(Yb + (int64_t)row * W + px) = v;
+        // (the row goes into the vector offset: with a scalar-register offset the 16-byte store still reads
+        // its data registers while the next vector instruction may already overwrite them, and the compiler
+        // does not guard that case)
+        const unsigned vo = (rowok && px < W) ? yoff + (unsigned)(row * W * 4) + 64u * j : PW_NOSTORE;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(pw_u32x4, v), yrsrc, vo, 0, 0);
     };
     auto stash = [&](const f32x4& v, int j) __attribute__((always_inline)) {           // GATE: keep my half of the strip, hand the other half over
         const bool mine = (j < HT) == (half == 0);
@@ -185,7 +232,7 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
             const float x2 = half == 0 ? other[q] : hv;
             o[q] = gelu_erf(x1) * x2;
         }
-        store_tile(o, row, half * HT + jh);
+        store_tile(o, row >= 0 ? row : 0, half * HT + jh, row >= 0);
     };
     auto finalize = [&](int row) __attribute__((always_inline)) {
 #pragma unroll
@@ -196,7 +243,7 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
     const bool in_l = px0 - 1 >= 0, in_r = px0 + WT < W;
 
 #pragma unroll
-    for (int i = 0; i < PW_STAGES - 1; ++i) issue(i < nq ? i : nq - 1, i);
+    for (int i = 0; i < PW_STAGES - 1; ++i) issue();
     int qc = 0, stage_c = 0;                             // chunk being consumed and its stage
 
     // ---- the depthwise phase of a finished row, cut into pieces ----
@@ -212,24 +259,23 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
         hlp += __shfl_xor(hlp, 32); hrp += __shfl_xor(hrp, 32);
         const float* sm = statm + (prow & 1) * ROWF;
         const float* sr = statr + (prow & 1) * ROWF;
-        float tl = 0.f, rl = 1.f, tr = 0.f, rr = 1.f;
-        if (a.ln_mode != 0) { tl = sm[3]; rl = sr[3]; tr = sm[4 + WT]; rr = sr[4 + WT]; }
-        hlf = in_l ? fmaf(rl, fmaf(tl, lns, hlp), lnc) : 0.f;
-        hrf = in_r ? fmaf(rr, fmaf(tr, lns, hrp), lnc) : 0.f;
+        const float tl = sm[3], rl = sr[3], tr = sm[4 + WT], rr = sr[4 + WT];     // (0, 1) without LayerNorm
+        hlf = (in_l && prow >= 0) ? fmaf(rl, fmaf(tl, lns, hlp), lnc) : 0.f;
+        hrf = (in_r && prow >= 0) ? fmaf(rr, fmaf(tr, lns, hrp), lnc) : 0.f;
     };
     // 1x1 output of a tile: LayerNorm constants and bias, then zero outside the image
     auto piece_finish = [&](int j) __attribute__((always_inline)) {
         const int px = px0 + 16 * j + 4 * kk;
-        f32x4 tco = {0.f, 0.f, 0.f, 0.f}, rstd = {1.f, 1.f, 1.f, 1.f};
-        if (a.ln_mode != 0) {
-            tco = *reinterpret_cast<const f32x4*>(&statm[(prow & 1) * ROWF + 4 + 16 * j + 4 * kk]);
-            rstd = *reinterpret_cast<const f32x4*>(&statr[(prow & 1) * ROWF + 4 + 16 * j + 4 * kk]);
-        }
+        // without LayerNorm the buffers hold (0, 1): the expression is then tp + lnc exactly
+        const f32x4 tco = *reinterpret_cast<const f32x4*>(&statm[(prow & 1) * ROWF + 4 + 16 * j + 4 * kk]);
+        const f32x4 rstd = *reinterpret_cast<const f32x4*>(&statr[(prow & 1) * ROWF + 4 + 16 * j + 4 * kk]);
+        const bool live = px < W && prow >= 0;        // W % 4 == 0: the four pixels are inside or outside together
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float v = fmaf(rstd[q], fmaf(tco[q], lns, tp[j][q]), lnc);
-            tp[j][q] = px < W ? v : 0.f;              // W % 4 == 0: the four pixels are inside or outside together
+            tp[j][q] = live ? v : 0.f;
         }
+        asm volatile("" : "+v"(tp[j]));               // computed here, not sunk to where it is used
     };
     // depthwise 3x3 of tile j: row prow's share of output rows prow-1 (now complete), prow and prow+1,
     // in four sub-pieces small enough to hide between two k-steps: (a) the six pixels e[0..5] (the one
@@ -253,22 +299,21 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
         f32x4 done;
 #pragma unroll
         for (int q = 0; q < 4; ++q) done[q] = fmaf(wv[8], e[q + 2], fmaf(wv[7], e[q + 1], fmaf(wv[6], e[q], Pst[j][q])));
-        if (prow - 1 >= R0 && prow - 1 < R1) {
-            if constexpr (GATE) stash(done, j);
-            else store_tile(done, prow - 1, j);
-        }
+        if constexpr (GATE) stash(done, j);           // rows outside the range are dropped when they are finalized
+        else store_tile(done, prow >= 1 ? prow - 1 : 0, j, prow - 1 >= R0 && prow - 1 < R1);
     };
     auto dw_c = [&](int j) __attribute__((always_inline)) {
         f32x4 qold;
         if constexpr (QLDS) qold = myq[j * 64]; else qold = Qst[j];
 #pragma unroll
         for (int q = 0; q < 4; ++q) Pst[j][q] = fmaf(wv[5], e[q + 2], fmaf(wv[4], e[q + 1], fmaf(wv[3], e[q], qold[q])));
+        asm volatile("" : "+v"(Pst[j]));
     };
     auto dw_d = [&](int j) __attribute__((always_inline)) {
         f32x4 qn;
 #pragma unroll
         for (int q = 0; q < 4; ++q) qn[q] = fmaf(wv[2], e[q + 2], fmaf(wv[1], e[q + 1], fmaf(wv[0], e[q], bq)));
-        if constexpr (QLDS) myq[j * 64] = qn; else Qst[j] = qn;
+        if constexpr (QLDS) myq[j * 64] = qn; else { Qst[j] = qn; asm volatile("" : "+v"(Qst[j])); }
     };
     auto piece_dw = [&](int j) __attribute__((always_inline)) { dw_a(j); dw_b(j); dw_c(j); dw_d(j); };
     // order: a tile is finished before the depthwise of its left neighbour needs its first pixel
@@ -298,11 +343,8 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
         if constexpr (GATE) {
             static_assert(!PIPE || (NC % 2 == 0 && HN == 2), "the split of the pieces assumes two halves of whole chunks");
             constexpr int HALF = KS / 2;
-            if (pend_row >= 0) {
-                PW_AT(0 * HALF / 6, finalize_tile(pend_row, 0))
-                PW_AT(1 * HALF / 6, finalize_tile(pend_row, 1))
-            }
-            if (prow < 0) return;
+            PW_AT(0 * HALF / 6, finalize_tile(pend_row, 0))
+            PW_AT(1 * HALF / 6, finalize_tile(pend_row, 1))
             PW_AT(2 * HALF / 6, piece_halo(); piece_finish(0))
             PW_AT(3 * HALF / 6, piece_finish(1))
             PW_AT(4 * HALF / 6, piece_finish(2))
@@ -316,7 +358,6 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
             PW_AT(HALF + 12 * HALF / 16, dw_a(3)) PW_AT(HALF + 13 * HALF / 16, dw_b(3))
             PW_AT(HALF + 14 * HALF / 16, dw_c(3)) PW_AT(HALF + 15 * HALF / 16, dw_d(3))
         } else {
-            if (prow < 0) return;
             constexpr int NP = 20;
             PW_AT(0 * KS / NP, piece_halo(); piece_finish(0))
             PW_AT(1 * KS / NP, piece_finish(1))
@@ -351,10 +392,7 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
             else if constexpr (NEWER == 9) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             else if constexpr (NEWER == 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)\n\ts_barrier" ::: "memory");
             else static_assert(NEWER == 3, "add the wait count for this configuration");
-            {
-                const int qn = qc + PW_STAGES - 1 < nq ? qc + PW_STAGES - 1 : nq - 1;   // past the end: keeps the per-wave count fixed, rewrites identical data
-                issue(qn, qn % PW_STAGES);
-            }
+            issue();
             if constexpr (GATE && !PIPE) {
                 if (c == 0 && pend_row >= 0) { finalize(pend_row); pend_row = -1; }
             }
@@ -369,7 +407,13 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
             const unsigned hb = (unsigned)(uintptr_t)(pw_lptr)Xc;              // halo columns (same for 16 lanes)
             const unsigned wb = (unsigned)(uintptr_t)(pw_lptr)(mywl + c * CKS * 64);
             pw_f32x2 x01[3], x23[3], xh[3];
-            float wq[3];
+            float wq[3], xs[3][NTW];
+            unsigned sb[NTW];
+#pragma unroll
+            for (int jj = 0; jj < NTW; ++jj) {
+                const int sg = wave + jj * NW;
+                sb[jj] = tb + 64u * (sg < PW_NSG ? sg : PW_NSG - 1);      // waves beyond the last group read along, their sums are dropped
+            }
             auto fetch = [&](auto Sc) {
                 constexpr int S = decltype(Sc)::value, SET = S % 3;
                 const unsigned tbs = tb + S * 4 * ROWF * 4, hbs = hb + S * 4 * ROWF * 4, wbs = wb;
@@ -380,6 +424,13 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
                 asm volatile("ds_read2_b32 %0, %1 offset0:36 offset1:52" : "=v"(r23) : "v"(tbs));
                 asm volatile("ds_read2_b32 %0, %1 offset0:3 offset1:68" : "=v"(rh) : "v"(hbs));
                 asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(rw) : "v"(wbs), "n"(S * 256));
+                // this wave's share of the LayerNorm statistics: one ring column per lane and k-step
+                pw_static_for<0, NTF>([&](auto Jc) {
+                    constexpr int JJ = decltype(Jc)::value;
+                    float& rs = xs[SET][JJ];
+                    const unsigned sbj = sb[JJ];
+                    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(rs) : "v"(sbj), "n"(S * 4 * ROWF * 4));
+                });
             };
             static_assert(T == 4 && WT == 64 && CKS >= 3, "the hand-scheduled k loop is written for 4 tiles");
             fetch(std::integral_constant<int, 0>{});
@@ -390,26 +441,44 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
                 // reads of the (up to two) later steps may still be outstanding: 4 instructions each
                 pw_f32x2 &r01 = x01[SET], &r23 = x23[SET], &rh = xh[SET];
                 float& rw = wq[SET];
-                if constexpr (S + 2 < CKS) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(r01), "+v"(r23), "+v"(rh), "+v"(rw));
-                else if constexpr (S + 1 < CKS) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(r01), "+v"(r23), "+v"(rh), "+v"(rw));
-                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r01), "+v"(r23), "+v"(rh), "+v"(rw));
+                constexpr int LATER = (S + 2 < CKS ? 2 : S + 1 < CKS ? 1 : 0) * (4 + NTF);      // reads of the later steps
+                static_assert(LATER <= 15, "lgkmcnt is a 4-bit counter");
+                // (every register is named once: a register tied twice is copied BEFORE the wait, i.e. before its read has landed)
+                float& rs0 = xs[SET][0];
+                static_assert(NTW <= 2, "name every statistics register in the wait");
+                if constexpr (NTF == 0) {
+                    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(r01), "+v"(r23), "+v"(rh), "+v"(rw) : "n"(LATER));
+                } else if constexpr (NTF == 1) {
+                    asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(r01), "+v"(r23), "+v"(rh), "+v"(rw), "+v"(rs0) : "n"(LATER));
+                } else {
+                    float& rs1 = xs[SET][NTW - 1];
+                    asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(r01), "+v"(r23), "+v"(rh), "+v"(rw), "+v"(rs0), "+v"(rs1) : "n"(LATER));
+                }
                 acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(x01[SET][0], wq[SET], acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(x01[SET][1], wq[SET], acc[1], 0, 0, 0);
                 acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(x23[SET][0], wq[SET], acc[2], 0, 0, 0);
                 acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(x23[SET][1], wq[SET], acc[3], 0, 0, 0);
                 hl = fmaf(wq[SET], xh[SET][0], hl);
                 hr = fmaf(wq[SET], xh[SET][1], hr);
+#pragma unroll
+                for (int jj = 0; jj < NTF; ++jj) {
+                    st[jj][0] += xs[SET][jj];
+                    st[jj][1] = fmaf(xs[SET][jj], xs[SET][jj], st[jj][1]);
+                }
                 if constexpr (PIPE) epi_piece(c * CKS + S);
             });
-            if (a.ln_mode != 0) {
+            if constexpr (!SFETCH) {
+                if (a.ln_mode != 0) {
 #pragma unroll
-                for (int jj = 0; jj < NTW; ++jj) {
-                    const int sg = wave + jj * NW;
-                    if (sg < PW_NSG) {
+                    for (int jj = 0; jj < NTW; ++jj) {
+                        const int sg = wave + jj * NW;
+                        if (sg < PW_NSG) {
 #pragma unroll
-                        for (int s = 0; s < CKS; ++s) {
-                            const float x = Xc[4 * s * ROWF + 16 * sg + lm];
-                            st[jj] += pw_f32x2{x, x * x};
+                            for (int s = 0; s < CKS; ++s) {
+                                const float x = Xc[4 * s * ROWF + 16 * sg + lm];
+                                st[jj][0] += x;
+                                st[jj][1] = fmaf(x, x, st[jj][1]);
+                            }
                         }
                     }
                 }
@@ -435,7 +504,9 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
                     }
                 }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // PIPE: the constants are first read by the pieces that ride on the next row, behind that row's
+            // first chunk barrier -- no barrier of their own
+            if constexpr (!SFETCH) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         }
         if constexpr (GATE && PIPE) {
             // the pieces that rode on this row finished output row prow-1 (handed over, final after the next barrier)
@@ -459,6 +530,8 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
             if (pend_row >= 0) finalize(pend_row);
             pend_row = -1;
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // partners are done reading before the next hand-over
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the last row's LayerNorm constants
         }
         if (prow >= 0) {
 #pragma unroll
@@ -483,7 +556,7 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
             finalize(H - 1);
         } else {
 #pragma unroll
-            for (int j = 0; j < T; ++j) store_tile(Pst[j], H - 1, j);
+            for (int j = 0; j < T; ++j) store_tile(Pst[j], H - 1, j, true);
         }
     }
 }
