@@ -138,6 +138,7 @@ struct AttnBufs {
     float *t, *qkv, *attn, *ghat, *nq, *nk, *mfold;
     // scratch
     float *gram_part, *sqq_part, *sqk_part, *fold;
+    float *gram_red, *sqq_red, *sqk_red;     // pre-reduced slabs when the pixel range is split more than 16 ways
     NtPlan plan;
 };
 
@@ -156,10 +157,24 @@ static void attn_carve_ws(const rst_block_desc* d, bool have_saved, Carver& cv, 
     const int64_t N = (int64_t)d->H * d->W;
     const int c = d->C / d->heads;
     const int BH = d->B * d->heads;
-    b.plan = gemm_nt_plan(c, c, N, BH, 16);     // the softmax kernel adds the Gram slabs itself
+    // Up to 16 pixel splits the softmax kernel adds the Gram slabs itself.  A few large samples (one
+    // full frame: BH = 1, N = 8.3 M) need far more splits than that to fill the chip; their slabs are
+    // summed by a reduction pass first.
+    {
+        const NtPlan probe = gemm_nt_plan(c, c, N, BH, 16);
+        const int64_t blocks16 = (int64_t)probe.d1.blocks * probe.d2.blocks * BH * probe.splits;
+        b.plan = blocks16 >= 256 ? probe : gemm_nt_plan(c, c, N, BH, 0);
+    }
     b.gram_part = cv.floats(gemm_nt_partial_floats(b.plan, c, c, BH));
     b.sqq_part = cv.floats((size_t)BH * b.plan.splits * c);
     b.sqk_part = cv.floats((size_t)BH * b.plan.splits * c);
+    if (b.plan.splits > 16) {
+        b.gram_red = cv.floats((size_t)BH * c * c);
+        b.sqq_red = cv.floats((size_t)BH * c);
+        b.sqk_red = cv.floats((size_t)BH * c);
+    } else {
+        b.gram_red = b.sqq_red = b.sqk_red = nullptr;
+    }
     b.fold = cv.floats(ln_fold_floats(3 * d->C, d->C));
     if (!have_saved) {
         b.t = cv.floats((size_t)d->B * 3 * d->C * N);
@@ -223,8 +238,16 @@ static int attention_fwd(const rst_block_desc* d, const rst_block_params* p, con
     gt.M1 = c; gt.M2 = c; gt.N = N; gt.nb1 = B; gt.nb2 = heads;
     gt.partial = b.gram_part; gt.sqA_partial = b.sqq_part; gt.sqB_partial = b.sqk_part;
     RST_TRY(gemm_nt_launch(gt, b.plan, stream));
-    RST_TRY(attn_softmax_launch(b.gram_part, b.sqq_part, b.sqk_part, p->temperature, b.attn, b.ghat, b.nq, b.nk,
-                                B, heads, c, b.plan.splits, stream));
+    if (b.plan.splits > 16) {
+        RST_TRY(reduce_slabs_launch(b.gram_part, b.gram_red, (int64_t)c * c, B * heads, b.plan.splits, 0, stream));
+        RST_TRY(reduce_slabs_launch(b.sqq_part, b.sqq_red, c, B * heads, b.plan.splits, 0, stream));
+        RST_TRY(reduce_slabs_launch(b.sqk_part, b.sqk_red, c, B * heads, b.plan.splits, 0, stream));
+        RST_TRY(attn_softmax_launch(b.gram_red, b.sqq_red, b.sqk_red, p->temperature, b.attn, b.ghat, b.nq, b.nk,
+                                    B, heads, c, 1, stream));
+    } else {
+        RST_TRY(attn_softmax_launch(b.gram_part, b.sqq_part, b.sqk_part, p->temperature, b.attn, b.ghat, b.nq, b.nk,
+                                    B, heads, c, b.plan.splits, stream));
+    }
     RST_TRY(attn_fold_launch(p->proj_weight, b.attn, b.mfold, B, C, heads, c, stream));
 
     // y = Mfold[b] v (+bias) (+residual)

@@ -107,3 +107,27 @@ def test_unfused_pair_still_matches():
                        env=env, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("case", [("one_sample_c48", 48, 1, "WithBias", False, 1, 96, 96),
+                                  ("one_sample_c96h2", 96, 2, "BiasFree", True, 1, 80, 128)], ids=lambda c: c[0])
+def test_single_large_sample_many_pixel_splits(case):
+    """One sample with many pixels (a full frame is the extreme): the Gram reduction is then split into more
+    pixel ranges than the softmax kernel adds by itself and goes through a slab reduction first.  Forward
+    (inference and training path) and input gradient against the fp64 oracle."""
+    from oracle import restormer_oracle as orc
+    tag, dim, heads, ln_type, bias, b, h, w = case
+    blk, x, r = _block(case)
+    sd64, x64, r64 = recipe.block_case_tensors(case, torch.float64)
+    with torch.no_grad():
+        got = blk(x)
+    x64 = x64.clone().requires_grad_(True)
+    ref = orc.transformer_block(x64, sd64, "", heads)
+    (ref * r64).sum().backward()
+    scale = ref.detach().abs().max()
+    assert float((got.double().cpu() - ref.detach()).abs().max() / scale) < TOL, tag
+    xg = x.detach().clone().requires_grad_(True)
+    out = blk(xg)
+    (out * r).sum().backward()
+    assert float((out.detach().double().cpu() - ref.detach()).abs().max() / scale) < TOL, tag
+    assert float((xg.grad.double().cpu() - x64.grad).abs().max() / x64.grad.abs().max()) < TOL, tag

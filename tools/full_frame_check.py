@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""One untiled full frame (default 1 x 3 x 2160 x 3840, fp32) through the HIP network on one GPU:
+time, peak memory, and the result against the CPU oracle on the same input.
+usage: python tools/full_frame_check.py [H W] [--no-oracle]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+
+
+def main():
+    nums = [int(a) for a in sys.argv[1:] if a.isdigit()]
+    H, W = (nums + [2160, 3840])[:2] if len(nums) >= 2 else (2160, 3840)
+    net = bench.build_model(0).cuda().eval()
+    x = torch.rand(1, 3, H, W, generator=torch.Generator().manual_seed(7))
+    xg = x.cuda()
+    with torch.no_grad():
+        net(xg)                                   # warm-up (MIOpen solver search, workspaces)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        t0 = time.perf_counter()
+        got = net(xg)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    print(f"frame {H}x{W}: {dt*1e3:.1f} ms, {H*W/dt/1e6:.2f} MP/s, peak HBM {torch.cuda.max_memory_allocated()/2**30:.1f} GiB, "
+          f"finite={bool(torch.isfinite(got).all())}", flush=True)
+    if "--no-oracle" in sys.argv:
+        return
+    from oracle import restormer_oracle as orc
+    torch.set_num_threads(int(os.environ.get("OMP_NUM_THREADS", "16")))
+    sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ref = orc.restormer_forward(x, sd)
+    print(f"oracle (fp32, CPU): {time.perf_counter()-t0:.1f} s", flush=True)
+    err = float((got.cpu().double() - ref.double()).abs().max() / ref.double().abs().max())
+    print(f"max rel err vs oracle: {err:.3e}", flush=True)
+    assert err < 1e-4
+
+
+if __name__ == "__main__":
+    main()
