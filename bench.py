@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Restormer throughput on MI355X: input megapixels per second.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode infer|train]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode infer|train|tiled|frame]
 
 Default workload (one GPU): Restormer(inp_channels=3, out_channels=3, dim=48), fp32
 inference on a synthetic batch of 16 x 3 x 256 x 256 (the configuration the
@@ -11,7 +11,9 @@ rank runs the same-size batch of its own (independent samples: no data-path
 collective), so the scaling is weak; time is the maximum over ranks between two
 barriers.  ``--mode train`` times the reference's training step instead
 (forward, L1, backward, gradient all-reduce over RCCL, clip, Adam) at 8 x 3 x 128 x 128
-per GPU.
+per GPU.  ``--mode tiled`` is one 1 x 3 x 2048 x 2048 image in 256-pixel tiles with 32 pixels of overlap,
+the tiles dealt round-robin to the ranks and the cores gathered on rank 0 (total work fixed: strong scaling);
+``--mode frame`` is one untiled 1 x 3 x 2160 x 3840 frame per GPU.
 
 Rank 0 prints one JSON line.  ``roofline`` is measured by a separate pass with the
 library's per-kernel event timers (HIP events on the launch stream around every
@@ -169,7 +171,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", choices=["infer", "train"], default="infer")
+    ap.add_argument("--mode", choices=["infer", "train", "tiled", "frame"], default="infer")
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--size", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -189,6 +191,28 @@ def main():
                 return net(x)
         workload = f"Restormer(3,3,dim=48) fp32 inference, {B}x3x{S}x{S} per GPU"
         metric = "restormer_inference_megapixels_per_sec"
+    elif args.mode in ("tiled", "frame"):
+        from superresolution_amd.parallel import tiled_inference
+        net.eval()
+        if args.mode == "tiled":
+            Hh = Ww = args.size or 2048
+            seed = 100                       # every rank holds the same image
+        else:
+            Hh, Ww = (args.size, args.size) if args.size else (2160, 3840)
+            seed = 100 + rank
+        x = torch.rand(1, 3, Hh, Ww, device=dev, generator=torch.Generator(device=dev).manual_seed(seed))
+
+        def step():
+            with torch.no_grad():
+                if args.mode == "tiled":
+                    return tiled_inference(net, x, tile=256, overlap=32, rank=rank, world=world, tile_batch=args.batch or 16)
+                return net(x)
+        scaling = "strong" if args.mode == "tiled" else "weak"
+        pixels = Hh * Ww * (1 if args.mode == "tiled" else world)
+        workload = (f"Restormer(3,3,dim=48) fp32 tiled inference of one 1x3x{Hh}x{Ww} image, 256-px tiles + 32-px overlap, tiles sharded over the GPUs"
+                    if args.mode == "tiled" else f"Restormer(3,3,dim=48) fp32 untiled inference, one 1x3x{Hh}x{Ww} frame per GPU")
+        metric = "restormer_inference_megapixels_per_sec"
+        B, S = 1, Hh
     else:
         from superresolution_amd.parallel import DataParallelTrainer
         B, S = args.batch or 8, args.size or 128
@@ -211,15 +235,19 @@ def main():
     barrier(world)
     elapsed = max_over_ranks(time.perf_counter() - t0, world)
 
-    mp = world * B * S * S * args.steps / 1e6
+    if args.mode in ("tiled", "frame"):
+        mp = pixels * args.steps / 1e6
+    else:
+        scaling = "weak"
+        mp = world * B * S * S * args.steps / 1e6
     out = {
         "metric": metric, "value": round(mp / elapsed, 3), "unit": "MP/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": workload, "global_batch": world * B, "input_hw": [S, S], "parallelism": f"dp{world}",
+        "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": workload, "global_batch": world * B, "input_hw": [Hh, Ww] if args.mode in ("tiled", "frame") else [S, S], "parallelism": f"dp{world}",
                    "weights": "default init, seed 0"},
     }
-    if rank != 0 and args.mode == "train":
+    if rank != 0 and args.mode in ("train", "tiled"):
         step()          # the profiled extra step on rank 0 contains collectives: every rank takes part
     if rank == 0:
         prof = kernel_profile(step)
