@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Restormer throughput on MI355X: input megapixels per second.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode infer|train|tiled|frame]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode infer|train|tiled|frame|frame_sharded]
 
 Default workload (one GPU): Restormer(inp_channels=3, out_channels=3, dim=48), fp32
 inference on a synthetic batch of 16 x 3 x 256 x 256 (the configuration the
@@ -13,7 +13,8 @@ barriers.  ``--mode train`` times the reference's training step instead
 (forward, L1, backward, gradient all-reduce over RCCL, clip, Adam) at 8 x 3 x 128 x 128
 per GPU.  ``--mode tiled`` is one 1 x 3 x 2048 x 2048 image in 256-pixel tiles with 32 pixels of overlap,
 the tiles dealt round-robin to the ranks and the cores gathered on rank 0 (total work fixed: strong scaling);
-``--mode frame`` is one untiled 1 x 3 x 2160 x 3840 frame per GPU.
+``--mode frame`` is one untiled 1 x 3 x 2160 x 3840 frame per GPU; ``--mode frame_sharded`` is ONE such frame whose
+rows are split over the GPUs, exact (per block one all-reduce of the attention's sums, halo rows point-to-point).
 
 Rank 0 prints one JSON line.  ``roofline`` is measured by a separate pass with the
 library's per-kernel event timers (HIP events on the launch stream around every
@@ -171,7 +172,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--mode", choices=["infer", "train", "tiled", "frame"], default="infer")
+    ap.add_argument("--mode", choices=["infer", "train", "tiled", "frame", "frame_sharded"], default="infer")
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--size", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -191,26 +192,30 @@ def main():
                 return net(x)
         workload = f"Restormer(3,3,dim=48) fp32 inference, {B}x3x{S}x{S} per GPU"
         metric = "restormer_inference_megapixels_per_sec"
-    elif args.mode in ("tiled", "frame"):
-        from superresolution_amd.parallel import tiled_inference
+    elif args.mode in ("tiled", "frame", "frame_sharded"):
+        from superresolution_amd.parallel import sharded_frame_inference, tiled_inference
         net.eval()
         if args.mode == "tiled":
             Hh = Ww = args.size or 2048
             seed = 100                       # every rank holds the same image
         else:
             Hh, Ww = (args.size, args.size) if args.size else (2160, 3840)
-            seed = 100 + rank
+            seed = 100 if args.mode == "frame_sharded" else 100 + rank
         x = torch.rand(1, 3, Hh, Ww, device=dev, generator=torch.Generator(device=dev).manual_seed(seed))
 
         def step():
             with torch.no_grad():
                 if args.mode == "tiled":
                     return tiled_inference(net, x, tile=256, overlap=32, rank=rank, world=world, tile_batch=args.batch or 16)
+                if args.mode == "frame_sharded":
+                    return sharded_frame_inference(net, x, rank, world, gather=True)
                 return net(x)
-        scaling = "strong" if args.mode == "tiled" else "weak"
-        pixels = Hh * Ww * (1 if args.mode == "tiled" else world)
+        scaling = "weak" if args.mode == "frame" else "strong"
+        pixels = Hh * Ww * (world if args.mode == "frame" else 1)
         workload = (f"Restormer(3,3,dim=48) fp32 tiled inference of one 1x3x{Hh}x{Ww} image, 256-px tiles + 32-px overlap, tiles sharded over the GPUs"
-                    if args.mode == "tiled" else f"Restormer(3,3,dim=48) fp32 untiled inference, one 1x3x{Hh}x{Ww} frame per GPU")
+                    if args.mode == "tiled" else
+                    f"Restormer(3,3,dim=48) fp32 exact inference of one 1x3x{Hh}x{Ww} frame, rows sharded over the GPUs, output gathered on rank 0"
+                    if args.mode == "frame_sharded" else f"Restormer(3,3,dim=48) fp32 untiled inference, one 1x3x{Hh}x{Ww} frame per GPU")
         metric = "restormer_inference_megapixels_per_sec"
         B, S = 1, Hh
     else:
@@ -235,7 +240,7 @@ def main():
     barrier(world)
     elapsed = max_over_ranks(time.perf_counter() - t0, world)
 
-    if args.mode in ("tiled", "frame"):
+    if args.mode in ("tiled", "frame", "frame_sharded"):
         mp = pixels * args.steps / 1e6
     else:
         scaling = "weak"
@@ -244,10 +249,10 @@ def main():
         "metric": metric, "value": round(mp / elapsed, 3), "unit": "MP/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
         "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": workload, "global_batch": world * B, "input_hw": [Hh, Ww] if args.mode in ("tiled", "frame") else [S, S], "parallelism": f"dp{world}",
+        "config": {"workload": workload, "global_batch": world * B, "input_hw": [Hh, Ww] if args.mode in ("tiled", "frame", "frame_sharded") else [S, S], "parallelism": {"tiled": f"tiles{world}", "frame_sharded": f"rows{world}"}.get(args.mode, f"dp{world}"),
                    "weights": "default init, seed 0"},
     }
-    if rank != 0 and args.mode in ("train", "tiled"):
+    if rank != 0 and args.mode in ("train", "tiled", "frame_sharded"):
         step()          # the profiled extra step on rank 0 contains collectives: every rank takes part
     if rank == 0:
         prof = kernel_profile(step)

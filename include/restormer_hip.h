@@ -220,6 +220,34 @@ int rst_block_bwd(const rst_block_desc* desc, const rst_block_params* params,
                   void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* One TransformerBlock of an image whose ROWS are split over several devices */
+/* (inference only) -- the same TransformerBlock.forward,                     */
+/* model/Restromer.py:163-167, whose attention (model/Restromer.py:128-150)   */
+/* sums q.k^T and the norms of q and k over ALL pixels: the sums are the only */
+/* thing the devices have to exchange inside a block.                         */
+/*   desc->H = rows of the local slab INCLUDING halo rows (two on every side  */
+/*   that has a neighbour: the block contains two depthwise 3x3 convolutions); */
+/*   [row0, row1) = the rows this device owns.                                 */
+/*   1. rst_block_shard_fwd_stats: qkv of the slab (kept in the workspace) and */
+/*      this device's share of the sums over its own rows ->                   */
+/*      stats[B*heads*c*c | B*C | B*C]  (Gram, |q|^2, |k|^2; c = C / heads).   */
+/*   2. the caller adds `stats` over the devices (one all-reduce);             */
+/*   3. rst_block_shard_fwd_apply with the summed stats and the SAME, untouched */
+/*      workspace: y = block(x) on the slab; rows closer than two rows to a    */
+/*      cut are not valid and are to be refreshed from the neighbour.          */
+/* y may alias x.  With one device (row0 = 0, row1 = H) the pair equals        */
+/* rst_block_fwd.                                                              */
+/* ------------------------------------------------------------------------- */
+size_t rst_block_shard_workspace_bytes(const rst_block_desc* desc);
+size_t rst_block_shard_stats_floats(const rst_block_desc* desc);
+int rst_block_shard_fwd_stats(const rst_block_desc* desc, const rst_block_params* params,
+                              const float* x, int32_t row0, int32_t row1, float* stats,
+                              void* workspace, size_t workspace_bytes, void* stream);
+int rst_block_shard_fwd_apply(const rst_block_desc* desc, const rst_block_params* params,
+                              const float* x, const float* stats, float* y,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* Per-kernel timing aid.  No counterpart in the reference (it has no timing   */
 /* code on this path); used by bench.py for the roofline numbers.  Between     */
 /* begin and end every kernel launch of this library is bracketed by HIP       */

@@ -72,6 +72,10 @@ SIGNATURES = {
     "rst_block_saved_bytes": (c_size_t, [_DESC]),
     "rst_block_fwd": (c_int32, [_DESC, _PAR, _P, _P, _P, _P, c_size_t, _P]),
     "rst_block_bwd_workspace_bytes": (c_size_t, [_DESC]),
+    "rst_block_shard_workspace_bytes": (c_size_t, [_DESC]),
+    "rst_block_shard_stats_floats": (c_size_t, [_DESC]),
+    "rst_block_shard_fwd_stats": (c_int32, [_DESC, _PAR, _P, c_int32, c_int32, _P, _P, c_size_t, _P]),
+    "rst_block_shard_fwd_apply": (c_int32, [_DESC, _PAR, _P, _P, _P, _P, c_size_t, _P]),
     "rst_profile_begin": (c_int32, []),
     "rst_profile_end": (c_int32, [c_char_p, c_size_t]),
     "rst_block_bwd": (c_int32, [_DESC, _PAR, _P, _P, _P, _P, _GR, _P, c_size_t, _P]),

@@ -196,6 +196,11 @@ static size_t attention_saved_bytes(const rst_block_desc* d) {
     return cv.total();
 }
 
+static int attention_qkv(const rst_block_desc* d, const rst_block_params* p, const float* x, AttnBufs& b, bool keep_t,
+                         const LnIn* ln, hipStream_t stream);
+static int attention_tail(const rst_block_desc* d, const rst_block_params* p, AttnBufs& b, const float* residual, float* y,
+                          int row0, int row1, const float* stats, hipStream_t stream);
+
 // `ln` (optional): x is the un-normalised input and the LayerNorm in front of the qkv convolution is applied here
 static int attention_fwd(const rst_block_desc* d, const rst_block_params* p, const float* x, const float* residual,
                          float* y, void* saved, void* ws, size_t ws_bytes, hipStream_t stream, const LnIn* ln = nullptr) {
@@ -211,9 +216,17 @@ static int attention_fwd(const rst_block_desc* d, const rst_block_params* p, con
     Carver cw(ws);
     attn_carve_ws(d, saved != nullptr, cw, b);
 
-    // t = W_qkv x (+bias);  qkv = dw3x3(t)
+    RST_TRY(attention_qkv(d, p, x, b, saved != nullptr, ln, stream));
+    return attention_tail(d, p, b, residual, y, 0, d->H, nullptr, stream);
+}
+
+// t = W_qkv x (+bias);  qkv = dw3x3(t)
+static int attention_qkv(const rst_block_desc* d, const rst_block_params* p, const float* x, AttnBufs& b, bool keep_t,
+                         const LnIn* ln, hipStream_t stream) {
+    const int B = d->B, C = d->C;
+    const int64_t N = (int64_t)d->H * d->W;
     bool fused = false;
-    if (!saved)
+    if (!keep_t)
         RST_TRY(ln_pw_dw(ln, p->qkv_weight, d->conv_bias ? p->qkv_bias : nullptr, p->qkv_dw_weight,
                          d->conv_bias ? p->qkv_dw_bias : nullptr, 3 * C, C, 0, x, b.qkv, B, d->H, d->W, b.fold, stream, &fused));
     if (!fused) {
@@ -230,14 +243,34 @@ static int attention_fwd(const rst_block_desc* d, const rst_block_params* p, con
         dw.y = b.qkv; dw.y_bstride = (int64_t)3 * C * N; dw.B = B; dw.C = 3 * C; dw.H = d->H; dw.W = d->W; dw.flip = 0;
         RST_TRY(dwconv_fwd_launch(dw, stream));
     }
+    return RST_OK;
+}
 
-    // Gram matrices and squared row norms, split over the pixels
+// Gram matrices and squared row norms over the rows [row0, row1) of every sample, split over the pixels
+static int attention_gram(const rst_block_desc* d, const AttnBufs& b, const NtPlan& plan, int row0, int row1,
+                          float* gram_part, float* sqq_part, float* sqk_part, hipStream_t stream) {
+    const int B = d->B, C = d->C, heads = d->heads, c = C / heads;
+    const int64_t N = (int64_t)d->H * d->W, off = (int64_t)row0 * d->W;
     GemmNT gt{};
-    gt.A = b.qkv;                      gt.a_s1 = (int64_t)3 * C * N; gt.a_s2 = (int64_t)c * N; gt.lda = N;
-    gt.Bm = b.qkv + (int64_t)C * N;    gt.b_s1 = (int64_t)3 * C * N; gt.b_s2 = (int64_t)c * N; gt.ldb = N;
-    gt.M1 = c; gt.M2 = c; gt.N = N; gt.nb1 = B; gt.nb2 = heads;
-    gt.partial = b.gram_part; gt.sqA_partial = b.sqq_part; gt.sqB_partial = b.sqk_part;
-    RST_TRY(gemm_nt_launch(gt, b.plan, stream));
+    gt.A = b.qkv + off;                      gt.a_s1 = (int64_t)3 * C * N; gt.a_s2 = (int64_t)c * N; gt.lda = N;
+    gt.Bm = b.qkv + (int64_t)C * N + off;    gt.b_s1 = (int64_t)3 * C * N; gt.b_s2 = (int64_t)c * N; gt.ldb = N;
+    gt.M1 = c; gt.M2 = c; gt.N = (int64_t)(row1 - row0) * d->W; gt.nb1 = B; gt.nb2 = heads;
+    gt.partial = gram_part; gt.sqA_partial = sqq_part; gt.sqB_partial = sqk_part;
+    return gemm_nt_launch(gt, plan, stream);
+}
+
+// everything after the qkv tensor: Gram (unless `stats` brings the sums: [B*heads*c*c] Gram, [B*C] |q|^2, [B*C] |k|^2),
+// softmax, project_out folded into attn.V, residual
+static int attention_tail(const rst_block_desc* d, const rst_block_params* p, AttnBufs& b, const float* residual, float* y,
+                          int row0, int row1, const float* stats, hipStream_t stream) {
+    const int B = d->B, C = d->C, heads = d->heads, c = C / heads;
+    const int64_t N = (int64_t)d->H * d->W;
+    if (stats) {
+        const float* sq = stats + (size_t)B * heads * c * c;
+        RST_TRY(attn_softmax_launch(stats, sq, sq + (size_t)B * C, p->temperature, b.attn, b.ghat, b.nq, b.nk,
+                                    B, heads, c, 1, stream));
+    } else {
+    RST_TRY(attention_gram(d, b, b.plan, row0, row1, b.gram_part, b.sqq_part, b.sqk_part, stream));
     if (b.plan.splits > 16) {
         RST_TRY(reduce_slabs_launch(b.gram_part, b.gram_red, (int64_t)c * c, B * heads, b.plan.splits, 0, stream));
         RST_TRY(reduce_slabs_launch(b.sqq_part, b.sqq_red, c, B * heads, b.plan.splits, 0, stream));
@@ -247,6 +280,7 @@ static int attention_fwd(const rst_block_desc* d, const rst_block_params* p, con
     } else {
         RST_TRY(attn_softmax_launch(b.gram_part, b.sqq_part, b.sqk_part, p->temperature, b.attn, b.ghat, b.nq, b.nk,
                                     B, heads, c, b.plan.splits, stream));
+    }
     }
     RST_TRY(attn_fold_launch(p->proj_weight, b.attn, b.mfold, B, C, heads, c, stream));
 
@@ -548,6 +582,77 @@ static int block_fwd(const rst_block_desc* d, const rst_block_params* p, const f
     return ffn_fwd(d, p, xn2, x1, y, s.ffn, sub, sub_bytes, stream);
 }
 
+// ---- one block of a row-sharded image (inference): the global sums of the attention come in from outside ----
+// desc->H counts the rows of the local slab including its halo rows; [row0, row1) are the rows this device owns.
+struct ShardBufs { float* xn; void* sub; size_t sub_bytes; float *gram_part, *sqq_part, *sqk_part; NtPlan plan; };
+
+static void shard_carve(const rst_block_desc* d, int rows, Carver& cv, ShardBufs& sb) {
+    const int c = d->C / d->heads, BH = d->B * d->heads;
+    sb.xn = cv.floats((size_t)d->B * d->C * d->H * d->W);
+    sb.sub_bytes = max2(attention_ws_bytes(d), ffn_ws_bytes(d));
+    sb.sub = cv.bytes(sb.sub_bytes);
+    // sized for the whole slab (the number of pixel splits grows with the pixel count), planned for the owned rows
+    const NtPlan most = gemm_nt_plan(c, c, (int64_t)d->H * d->W, BH, 0);
+    sb.plan = gemm_nt_plan(c, c, (int64_t)rows * d->W, BH, 0);
+    sb.gram_part = cv.floats(gemm_nt_partial_floats(most, c, c, BH));
+    sb.sqq_part = cv.floats((size_t)BH * most.splits * c);
+    sb.sqk_part = cv.floats((size_t)BH * most.splits * c);
+}
+static size_t block_shard_ws_bytes(const rst_block_desc* d) {
+    Carver cv(nullptr); ShardBufs sb{};
+    shard_carve(d, d->H, cv, sb);
+    return cv.total();
+}
+static size_t block_shard_stats_floats(const rst_block_desc* d) {
+    const int c = d->C / d->heads;
+    return (size_t)d->B * d->heads * c * c + 2 * (size_t)d->B * d->C;
+}
+
+static int block_shard_check(const rst_block_desc* d, const rst_block_params* p, const void* ws, size_t ws_bytes, const char* who) {
+    RST_REQUIRE(p && p->norm1_weight && p->norm2_weight, "%s: null LayerNorm weight", who);
+    RST_REQUIRE(!d->ln_with_bias || (p->norm1_bias && p->norm2_bias), "%s: ln_with_bias set but a bias is null", who);
+    RST_REQUIRE(p->temperature && p->qkv_weight && p->qkv_dw_weight && p->proj_weight, "%s: null attention parameter", who);
+    RST_REQUIRE(!d->conv_bias || (p->qkv_bias && p->qkv_dw_bias && p->proj_bias), "%s: conv_bias set but a bias is null", who);
+    if (ws == nullptr || ws_bytes < block_shard_ws_bytes(d))
+        return fail(RST_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", who, ws_bytes, block_shard_ws_bytes(d));
+    return RST_OK;
+}
+
+// phase 1: qkv of the slab (kept in the workspace for phase 2), then this device's share of the Gram matrices and of
+// the squared norms of q and k over its own rows -> stats[B*heads*c*c | B*C | B*C]
+static int block_shard_stats(const rst_block_desc* d, const rst_block_params* p, const float* x, int row0, int row1,
+                             float* stats, void* ws, size_t ws_bytes, hipStream_t stream) {
+    RST_REQUIRE(x && stats, "block_shard_fwd_stats: null operand");
+    RST_REQUIRE(0 <= row0 && row0 < row1 && row1 <= d->H, "block_shard_fwd_stats: rows [%d, %d) outside the slab of %d rows", row0, row1, d->H);
+    RST_TRY(block_shard_check(d, p, ws, ws_bytes, "block_shard_fwd_stats"));
+    const int B = d->B, C = d->C, heads = d->heads, c = C / heads;
+    Carver cw(ws); ShardBufs sb{};
+    shard_carve(d, row1 - row0, cw, sb);
+    AttnBufs b{}; Carver ca(sb.sub);
+    attn_carve_ws(d, false, ca, b);
+    const LnIn ln1{p->norm1_weight, d->ln_with_bias ? p->norm1_bias : nullptr, sb.xn};
+    RST_TRY(attention_qkv(d, p, x, b, false, &ln1, stream));
+    RST_TRY(attention_gram(d, b, sb.plan, row0, row1, sb.gram_part, sb.sqq_part, sb.sqk_part, stream));
+    float* sq = stats + (size_t)B * heads * c * c;
+    RST_TRY(reduce_slabs_launch(sb.gram_part, stats, (int64_t)c * c, B * heads, sb.plan.splits, 0, stream));
+    RST_TRY(reduce_slabs_launch(sb.sqq_part, sq, c, B * heads, sb.plan.splits, 0, stream));
+    return reduce_slabs_launch(sb.sqk_part, sq + (size_t)B * C, c, B * heads, sb.plan.splits, 0, stream);
+}
+
+// phase 2: `stats` summed over all devices -> attention output + residual, then the feed-forward half
+static int block_shard_apply(const rst_block_desc* d, const rst_block_params* p, const float* x, const float* stats, float* y,
+                             void* ws, size_t ws_bytes, hipStream_t stream) {
+    RST_REQUIRE(x && stats && y, "block_shard_fwd_apply: null operand");
+    RST_TRY(block_shard_check(d, p, ws, ws_bytes, "block_shard_fwd_apply"));
+    Carver cw(ws); ShardBufs sb{};
+    shard_carve(d, d->H, cw, sb);
+    AttnBufs b{}; Carver ca(sb.sub);
+    attn_carve_ws(d, false, ca, b);                       // same carving as phase 1: b.qkv still holds the slab's qkv
+    RST_TRY(attention_tail(d, p, b, x, y, 0, d->H, stats, stream));
+    const LnIn ln2{p->norm2_weight, d->ln_with_bias ? p->norm2_bias : nullptr, sb.xn};
+    return ffn_fwd(d, p, y, y, y, nullptr, sb.sub, sb.sub_bytes, stream, &ln2);
+}
+
 static size_t block_bwd_ws_bytes(const rst_block_desc* d) {
     Carver cv(nullptr);
     const size_t n = (size_t)d->B * d->C * d->H * d->W;
@@ -727,6 +832,18 @@ int rst_block_fwd(const rst_block_desc* d, const rst_block_params* p, const floa
                   void* workspace, size_t workspace_bytes, void* stream) {
     RST_TRY(check_desc(d));
     return block_fwd(d, p, x, y, saved, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+size_t rst_block_shard_workspace_bytes(const rst_block_desc* d) { return check_desc(d) == RST_OK ? block_shard_ws_bytes(d) : 0; }
+size_t rst_block_shard_stats_floats(const rst_block_desc* d) { return check_desc(d) == RST_OK ? block_shard_stats_floats(d) : 0; }
+int rst_block_shard_fwd_stats(const rst_block_desc* d, const rst_block_params* p, const float* x, int32_t row0, int32_t row1,
+                              float* stats, void* workspace, size_t workspace_bytes, void* stream) {
+    RST_TRY(check_desc(d));
+    return block_shard_stats(d, p, x, row0, row1, stats, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+int rst_block_shard_fwd_apply(const rst_block_desc* d, const rst_block_params* p, const float* x, const float* stats, float* y,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+    RST_TRY(check_desc(d));
+    return block_shard_apply(d, p, x, stats, y, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 size_t rst_block_bwd_workspace_bytes(const rst_block_desc* d) { return check_desc(d) == RST_OK ? block_bwd_ws_bytes(d) : 0; }
 int rst_block_bwd(const rst_block_desc* d, const rst_block_params* p, const float* x, const float* dy, const void* saved,

@@ -244,7 +244,7 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
 
 #pragma unroll
     for (int i = 0; i < PW_STAGES - 1; ++i) issue();
-    int qc = 0, stage_c = 0;                             // chunk being consumed and its stage
+    int stage_c = 0;                             // chunk being consumed and its stage
 
     // ---- the depthwise phase of a finished row, cut into pieces ----
     // tp[] = the raw 1x1 accumulators of row `prow`, hlp/hrp its raw halo shares; their LayerNorm
@@ -483,7 +483,6 @@ pwdw_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
                     }
                 }
             }
-            ++qc;
             stage_c = stage_c == PW_STAGES - 1 ? 0 : stage_c + 1;
         }
 

@@ -394,3 +394,38 @@ def block_forward_inplace(x, heads, hidden, params: Dict[str, Optional[torch.Ten
     check(lib.rst_block_fwd(ctypes.byref(desc), ctypes.byref(par), _ptr(x), _ptr(x), None, _ptr(ws), ws.numel(), _stream()),
           "rst_block_fwd")
     return x
+
+
+def _shard_args(x, heads, hidden, params):
+    lib = _lib.load()
+    x = _require(x, "block x")
+    B, C, H, W = x.shape
+    tensors = {n: (None if params.get(n) is None else _require(params[n], n)) for n in PARAM_FIELDS}
+    desc = make_desc(B, C, H, W, heads, hidden, tensors["norm1_bias"] is not None, tensors["qkv_bias"] is not None)
+    par = _fill(BlockParams(), tensors)
+    ws = workspace(lib.rst_block_shard_workspace_bytes(ctypes.byref(desc)), x.device)
+    return lib, x, desc, par, ws, tensors
+
+
+def block_shard_stats(x, row0: int, row1: int, heads, hidden, params: Dict[str, Optional[torch.Tensor]]) -> torch.Tensor:
+    """Phase 1 of a TransformerBlock on a row slab of a larger image (inference): this device's share of the
+    attention's sums over all pixels (Gram matrices and squared norms of q and k, taken over rows [row0, row1)).
+    The caller adds the returned vector over the devices and hands it to `block_shard_apply`, with no other
+    operator of this library on the same stream in between (the slab's qkv waits in the shared workspace)."""
+    lib, x, desc, par, ws, keep = _shard_args(x, heads, hidden, params)
+    stats = torch.empty(lib.rst_block_shard_stats_floats(ctypes.byref(desc)), dtype=torch.float32, device=x.device)
+    check(lib.rst_block_shard_fwd_stats(ctypes.byref(desc), ctypes.byref(par), _ptr(x), int(row0), int(row1), _ptr(stats),
+                                        _ptr(ws), ws.numel(), _stream()), "rst_block_shard_fwd_stats")
+    return stats
+
+
+def block_shard_apply(x, stats, heads, hidden, params: Dict[str, Optional[torch.Tensor]]) -> torch.Tensor:
+    """Phase 2: the block applied to the slab in place, given the sums over all devices.  Rows closer than two
+    rows to a cut are not valid afterwards."""
+    lib, x, desc, par, ws, keep = _shard_args(x, heads, hidden, params)
+    stats = _require(stats, "stats")
+    if stats.numel() != lib.rst_block_shard_stats_floats(ctypes.byref(desc)):
+        raise RuntimeError(f"stats has {stats.numel()} elements, expected {lib.rst_block_shard_stats_floats(ctypes.byref(desc))}")
+    check(lib.rst_block_shard_fwd_apply(ctypes.byref(desc), ctypes.byref(par), _ptr(x), _ptr(stats), _ptr(x),
+                                        _ptr(ws), ws.numel(), _stream()), "rst_block_shard_fwd_apply")
+    return x

@@ -239,3 +239,179 @@ def tiled_inference(model: nn.Module, image: torch.Tensor, tile: int = 256, over
     if sizes[rank] > 0:
         dist.send(flat, dst=0, group=process_group)
     return None
+
+
+# ----------------------------------------------------------------------------
+# exact row-sharded inference of one frame
+# ----------------------------------------------------------------------------
+HALO = 2        # rows: a TransformerBlock holds two depthwise 3x3 convolutions, and halos are refreshed after every block
+
+
+def row_partition(h: int, world: int, multiple: int = 8) -> List[Tuple[int, int]]:
+    """Contiguous row ranges [a, b) per rank, cut at multiples of `multiple` (three 2x down-samplings), as even
+    as possible; every rank gets at least HALO rows at the coarsest level."""
+    units = h // multiple
+    if h % multiple or units < HALO * world:
+        raise ValueError(f"cannot cut {h} rows into {world} slabs of at least {HALO * multiple} rows in steps of {multiple}")
+    base, extra = divmod(units, world)
+    out, a = [], 0
+    for r in range(world):
+        b = a + base + (1 if r < extra else 0)
+        out.append((a * multiple, b * multiple))
+        a = b
+    return out
+
+
+class _Slab:
+    """Rows [lo, hi) of a level's tensor held by this rank; [a, b) are its own rows, the rest is halo."""
+
+    def __init__(self, interior: torch.Tensor, a: int, b: int, rows_total: int):
+        self.a, self.b, self.total = a, b, rows_total
+        self.lo, self.hi = max(a - HALO, 0), min(b + HALO, rows_total)
+        n, c, _, w = interior.shape
+        self.t = interior.new_empty((n, c, self.hi - self.lo, w))
+        self.t[:, :, self.r0:self.r1] = interior
+
+    @property
+    def r0(self) -> int:
+        return self.a - self.lo
+
+    @property
+    def r1(self) -> int:
+        return self.b - self.lo
+
+    def interior(self) -> torch.Tensor:
+        return self.t[:, :, self.r0:self.r1]
+
+
+def _exchange(pairs, group):
+    """pairs: list of (send_tensor or None, recv_tensor or None, peer).  NCCL moves device buffers directly; gloo
+    (CPU tests, two ranks on one card) has no device point-to-point, so the rows are staged through the host."""
+    staged = dist.get_backend(group) == "gloo"
+    ops_, keep = [], []
+    for send, recv, peer in pairs:
+        if send is not None:
+            s = send.cpu() if staged else send
+            keep.append(s)
+            ops_.append(dist.P2POp(dist.isend, s, peer, group))
+        if recv is not None:
+            r = torch.empty(recv.shape, dtype=recv.dtype) if staged else recv
+            keep.append((r, recv))
+            ops_.append(dist.P2POp(dist.irecv, r, peer, group))
+    if ops_:
+        for q in dist.batch_isend_irecv(ops_):
+            q.wait()
+    if staged:
+        for k in keep:
+            if isinstance(k, tuple):
+                k[1].copy_(k[0])
+
+
+def _refresh_halo(s: _Slab, rank: int, world: int, group) -> None:
+    """The halo rows of the slab <- the neighbours' outermost own rows (and the other way round)."""
+    if world == 1:
+        return
+    pairs, land = [], []
+    if s.a > 0:
+        up = torch.empty_like(s.t[:, :, :s.r0])
+        pairs.append((s.t[:, :, s.r0:s.r0 + HALO].contiguous(), up, rank - 1))
+        land.append((slice(0, s.r0), up))
+    if s.b < s.total:
+        dn = torch.empty_like(s.t[:, :, s.r1:])
+        pairs.append((s.t[:, :, s.r1 - HALO:s.r1].contiguous(), dn, rank + 1))
+        land.append((slice(s.r1, s.t.shape[2]), dn))
+    _exchange(pairs, group)
+    for sl, buf in land:
+        s.t[:, :, sl] = buf
+
+
+def sharded_frame_inference(model: nn.Module, image: torch.Tensor, rank: int = 0, world: int = 1, process_group=None,
+                            gather: bool = True) -> Optional[torch.Tensor]:
+    """EXACT x2 inference of one 1 x C x H x W frame whose rows are split over `world` GPUs (same result as the
+    network on the whole frame, up to summation order): each rank runs the network on its row slab plus two halo
+    rows; inside every TransformerBlock the only global quantities -- the Gram matrices q.k^T and the squared
+    norms of q and k of the channel attention -- are summed over the ranks by one small all-reduce
+    (`ops.block_shard_stats` / `ops.block_shard_apply`), and after every block and every resampling the halo rows
+    are refreshed from the neighbours (point-to-point, 2 rows x C x W each way).  Every rank passes the same
+    `image`; rank 0 returns the assembled output when `gather`, otherwise each rank returns its own rows."""
+    from . import ops
+    if image.dim() != 4 or image.shape[0] != 1:
+        raise ValueError("sharded_frame_inference expects a 1 x C x H x W image")
+    if getattr(model, "dual_pixel_task", False):
+        raise NotImplementedError("dual_pixel_task")
+    _, _, h, w = image.shape
+    if w % 8:
+        raise ValueError("W must be divisible by 8")
+    cuts = row_partition(h, world)
+    a, b = cuts[rank]
+
+    def slab(interior, factor_num, factor_den=1):
+        """interior rows at the level whose row count is h * num / den"""
+        s = _Slab(interior, a * factor_num // factor_den, b * factor_num // factor_den, h * factor_num // factor_den)
+        _refresh_halo(s, rank, world, process_group)
+        return s
+
+    def stage(blocks, s: _Slab) -> _Slab:
+        for blk in blocks:
+            heads, hidden, par = blk.attn.num_heads, blk.ffn.hidden_features, blk._params()
+            stats = ops.block_shard_stats(s.t, s.r0, s.r1, heads, hidden, par)
+            if world > 1:
+                dist.all_reduce(stats, group=process_group)
+            ops.block_shard_apply(s.t, stats, heads, hidden, par)
+            _refresh_halo(s, rank, world, process_group)
+        return s
+
+    def conv(s: _Slab, c: nn.Conv2d) -> torch.Tensor:
+        return F.conv2d(s.t, c.weight, c.bias, padding=1)            # rows next to a cut are wrong: cropped by the callers
+
+    def down(s: _Slab, mod, den) -> _Slab:                            # conv3x3 + PixelUnshuffle(2): rows / 2
+        y = ops.pixel_unshuffle2(conv(s, mod.body[0]))
+        lo = s.lo // 2
+        return slab(y[:, :, s.a // 2 - lo:s.b // 2 - lo], 1, den)
+
+    def up(s: _Slab, mod, den) -> _Slab:                              # conv3x3 + PixelShuffle(2): rows * 2
+        y = ops.pixel_shuffle2(conv(s, mod.body[0]))
+        lo = s.lo * 2
+        return slab(y[:, :, s.a * 2 - lo:s.b * 2 - lo], 1, den)
+
+    with torch.no_grad():
+        x0 = slab(image[:, :, a:b].contiguous(), 1)                  # input rows + halo (kept for the bilinear base)
+        e1 = slab(conv(x0, model.patch_embed.proj)[:, :, x0.r0:x0.r1], 1)
+        e1 = stage(model.encoder_level1, e1)
+        e2 = stage(model.encoder_level2, down(e1, model.down1_2, 2))
+        e3 = stage(model.encoder_level3, down(e2, model.down2_3, 4))
+        lat = stage(model.latent, down(e3, model.down3_4, 8))
+
+        d3 = up(lat, model.up4_3, 4)
+        d3.t = ops.conv1x1(torch.cat([d3.t, e3.t], 1), model.reduce_chan_level3.weight, model.reduce_chan_level3.bias)
+        d3 = stage(model.decoder_level3, d3)
+        d2 = up(d3, model.up3_2, 2)
+        d2.t = ops.conv1x1(torch.cat([d2.t, e2.t], 1), model.reduce_chan_level2.weight, model.reduce_chan_level2.bias)
+        d2 = stage(model.decoder_level2, d2)
+        d1 = up(d2, model.up2_1, 1)
+        d1.t = torch.cat([d1.t, e1.t], 1)
+        d1 = stage(model.refinement, stage(model.decoder_level1, d1))
+
+        # x2 tail on the slab: the halo of d1 (2 rows = 4 output rows) covers the last 3x3 convolution and the
+        # bilinear base without another exchange
+        upt = ops.pixel_shuffle2(conv(d1, model.output_upscale.body[0]))
+        base = F.interpolate(x0.t, scale_factor=2, mode="bilinear", align_corners=False)
+        if model.output.weight.shape[0] <= 4:
+            out = ops.conv3x3_fewout(upt, model.output.weight, model.output.bias, base)
+        else:
+            out = F.conv2d(upt, model.output.weight, model.output.bias, padding=1) + base
+        mine = out[:, :, 2 * d1.r0:2 * d1.r1].contiguous()
+
+    if world == 1 or not gather:
+        return mine
+    # rank 0 assembles the rows
+    if rank == 0:
+        canvas = mine.new_empty((1, mine.shape[1], 2 * h, 2 * w))
+        canvas[:, :, 2 * a:2 * b] = mine
+        bufs = [(canvas.new_empty((1, mine.shape[1], 2 * (cb - ca), 2 * w)), r) for r, (ca, cb) in enumerate(cuts) if r > 0]
+        _exchange([(None, buf, r) for buf, r in bufs], process_group)
+        for buf, r in bufs:
+            canvas[:, :, 2 * cuts[r][0]:2 * cuts[r][1]] = buf
+        return canvas
+    _exchange([(mine, None, 0)], process_group)
+    return None

@@ -1,0 +1,86 @@
+"""Exact row-sharded inference of one frame: every rank runs its row slab (+2 halo rows), the attention's sums over
+all pixels are all-reduced inside every block.  The result must equal the network on the whole frame."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CASES = {   # name: (dim, H, W)  -- dim 16 runs the separate kernels, dim 48 the fused 1x1 + depthwise ones (W >= 64)
+    "dim16": (16, 64, 96),
+    "dim48": (48, 64, 128),
+}
+
+
+def _net(dim):
+    from superresolution_amd.model.Restromer import Restormer
+    torch.manual_seed(3)
+    net = Restormer(inp_channels=3, out_channels=3, dim=dim, num_blocks=[1, 2, 1, 1], num_refinement_blocks=1,
+                    heads=[1, 2, 4, 8], bias=(dim == 16), LayerNorm_type="WithBias" if dim == 48 else "BiasFree")
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if name.endswith("temperature") or ".body.weight" in name:
+                p.copy_(torch.rand(p.shape, generator=g) + 0.5)
+    return net.cuda().eval()
+
+
+def _image(h, w):
+    return torch.rand(1, 3, h, w, generator=torch.Generator().manual_seed(9)).cuda()
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max())
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_one_rank_equals_whole_frame(name):
+    from superresolution_amd.parallel import sharded_frame_inference
+    dim, h, w = CASES[name]
+    net, x = _net(dim), _image(h, w)
+    with torch.no_grad():
+        ref = net(x)
+    got = sharded_frame_inference(net, x, 0, 1)
+    assert got.shape == ref.shape
+    assert _rel(got, ref) < 2e-6
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, name, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # both ranks share the one card: no RCCL here
+    from superresolution_amd.parallel import sharded_frame_inference
+    dim, h, w = CASES[name]
+    net, x = _net(dim), _image(h, w)
+    out = sharded_frame_inference(net, x, rank, world)
+    if rank == 0:
+        with torch.no_grad():
+            ref = net(x)
+        torch.save({"err": _rel(out, ref), "shape": tuple(out.shape), "ref_shape": tuple(ref.shape)}, out_path)
+    else:
+        assert out is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("name", list(CASES))
+def test_ranks_on_one_card_equal_whole_frame(name, world, tmp_path):
+    out_path = str(tmp_path / "r.pt")
+    mp.spawn(_worker, args=(world, _free_port(), name, out_path), nprocs=world, join=True)
+    r = torch.load(out_path)
+    assert r["shape"] == r["ref_shape"]
+    assert r["err"] < 2e-6, r

@@ -142,3 +142,43 @@ def test_tile_grid_covers_image_once(h, w, tile, ov):
     assert int(cover.min()) == 1 and int(cover.max()) == 1
     if (h, w, tile) == (2048, 2048, 256):
         assert len(tile_grid(h, w, tile, ov)) == 64
+
+
+# ---- row-sharded frame: partition and halo exchange (the block arithmetic itself needs the GPU) ----
+def test_row_partition():
+    from superresolution_amd.parallel import row_partition
+    assert row_partition(2160, 8)[0] == (0, 272) and row_partition(2160, 8)[-1][1] == 2160
+    assert all(a % 8 == 0 and b % 8 == 0 for a, b in row_partition(2160, 8))
+    assert row_partition(64, 1) == [(0, 64)]
+    with pytest.raises(ValueError):
+        row_partition(64, 8)           # 8 rows per rank at full resolution = 1 row at the coarsest level: too thin
+    with pytest.raises(ValueError):
+        row_partition(100, 2)
+
+
+def _halo_worker(rank, world, port, out_path):
+    from superresolution_amd import parallel
+    _init(rank, world, port)
+    full = torch.arange(2 * 5 * 48 * 7, dtype=torch.float32).reshape(2, 5, 48, 7)
+    a, b = parallel.row_partition(48, world)[rank]
+    s = parallel._Slab(full[:, :, a:b].clone(), a, b, 48)
+    s.t[:, :, :s.r0] = -1.0                     # halos start as garbage
+    s.t[:, :, s.r1:] = -1.0
+    parallel._refresh_halo(s, rank, world, None)
+    ok = torch.equal(s.t, full[:, :, s.lo:s.hi]) and (s.lo, s.hi) == (max(a - 2, 0), min(b + 2, 48))
+    # second refresh after the owners changed their rows
+    s.t[:, :, s.r0:s.r1] += 1000.0
+    parallel._refresh_halo(s, rank, world, None)
+    ok = ok and torch.equal(s.t, full[:, :, s.lo:s.hi] + 1000.0)
+    flags = [torch.zeros(1) for _ in range(world)]
+    dist.all_gather(flags, torch.tensor([1.0 if ok else 0.0]))
+    if rank == 0:
+        torch.save([float(f) for f in flags], out_path)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_halo_rows_come_from_the_neighbours(world, tmp_path):
+    out = str(tmp_path / "halo.pt")
+    mp.spawn(_halo_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert torch.load(out) == [1.0] * world
