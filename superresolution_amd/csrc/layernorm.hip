@@ -131,6 +131,43 @@ ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ weight, con
 // Blocks stride over tiles and keep per-channel partial sums of dw/db in
 // registers; one partial row per block goes to `partial` ([grid][2][C]) and a
 // second kernel adds the rows in a fixed order (deterministic).
+// Buffer-addressed vectors for the backward kernel: one descriptor per tensor and sample, the per-lane part of
+// the address is a single 32-bit offset shared by all channels, the channel plane comes in as a scalar offset
+// (flat 64-bit addresses for 24 channels x 3 tensors do not fit the register file).  A lane whose offset lies
+// outside the descriptor reads zeros and its stores are dropped.
+typedef unsigned ln_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned ln_u32x4 __attribute__((ext_vector_type(4)));
+template <int VEC>
+__device__ __forceinline__ void buf_load(float (&v)[VEC], __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    if constexpr (VEC == 4) {
+        const ln_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = __uint_as_float(t[i]);
+    } else if constexpr (VEC == 2) {
+        const ln_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+        v[0] = __uint_as_float(t[0]); v[1] = __uint_as_float(t[1]);
+    } else {
+        v[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+    }
+}
+// (the plane offset goes into the vector offset: a wide store with a scalar-register offset may still be reading
+// its data registers when the next vector instruction overwrites them)
+template <int VEC>
+__device__ __forceinline__ void buf_store(const float (&v)[VEC], __amdgpu_buffer_rsrc_t r, unsigned voff) {
+    if constexpr (VEC == 4) {
+        ln_u32x4 t;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = __float_as_uint(v[i]);
+        __builtin_amdgcn_raw_buffer_store_b128(t, r, voff, 0, 0);
+    } else if constexpr (VEC == 2) {
+        ln_u32x2 t;
+        t[0] = __float_as_uint(v[0]); t[1] = __float_as_uint(v[1]);
+        __builtin_amdgcn_raw_buffer_store_b64(t, r, voff, 0, 0);
+    } else {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0]), r, voff, 0, 0);
+    }
+}
+
 template <int VEC, int CPT>
 __global__ void __launch_bounds__(1024)
 ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ weight, int with_bias,
@@ -138,11 +175,18 @@ ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ weight, int
               float* __restrict__ partial, int C, int64_t N, int64_t tiles_per_sample, int64_t total_tiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int waves = blockDim.x >> 6;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     float* red0 = smem;
     float* red1 = smem + waves * 64 * VEC;
     const float invC = 1.0f / (float)C;
+    const unsigned plane = (unsigned)(N * 4);           // bytes per channel plane (C * N * 4 < 2^32, checked by the launcher)
+    const unsigned sample_bytes = (unsigned)((int64_t)C * N * 4);
+    constexpr int GRP = VEC == 4 ? 2 : 6;            // dy vectors in flight per lane and pass
+    static_assert(CPT % GRP == 0, "channel share must be whole groups");
 
+    // Registers hold the centred, normalised x of the tile and the parameter-gradient sums; dy is
+    // streamed twice (sums over the channels first, dx second -- the second read comes from the
+    // cache).  Holding dy as well does not fit 128 registers at 24 channels per wave and spills.
     float pw[CPT], pb[CPT];
 #pragma unroll
     for (int j = 0; j < CPT; ++j) { pw[j] = 0.f; pb[j] = 0.f; }
@@ -151,21 +195,25 @@ ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ weight, int
         const int64_t b = tile / tiles_per_sample;
         const int64_t p0 = (tile % tiles_per_sample) * (64 * VEC) + lane * VEC;
         const bool pix_ok = p0 < N;
-        const int64_t base = b * (int64_t)C * N + p0;
+        const unsigned voff = pix_ok ? (unsigned)(p0 * 4) : 0xFFFFFFF0u;
+        const int64_t sbase = b * (int64_t)C * N;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + sbase), 0, sample_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy + sbase), 0, sample_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t radd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((addend ? addend : dx) + sbase), 0, sample_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc(dx + sbase, 0, sample_bytes, 0x00020000);
 
-        float v[CPT][VEC], g[CPT][VEC];
+        float v[CPT][VEC];
         float s[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) s[i] = 0.f;
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
             const int c = wave + j * waves;
-            if (c < C && pix_ok) {
-                load_vec<VEC>(v[j], x + base + (int64_t)c * N);
-                load_vec<VEC>(g[j], dy + base + (int64_t)c * N);
+            if (c < C) {
+                buf_load<VEC>(v[j], rx, voff, (unsigned)c * plane);
             } else {
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) { v[j][i] = 0.f; g[j][i] = 0.f; }
+                for (int i = 0; i < VEC; ++i) v[j][i] = 0.f;
             }
 #pragma unroll
             for (int i = 0; i < VEC; ++i) s[i] += v[j][i];
@@ -177,65 +225,99 @@ ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ weight, int
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
             const int c = wave + j * waves;
-            if (c < C) {
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) { float d = v[j][i] - mu[i]; q[i] += d * d; }
+            for (int i = 0; i < VEC; ++i) {
+                const float d = c < C ? v[j][i] - mu[i] : 0.f;
+                v[j][i] = d;
+                q[i] += d * d;
             }
         }
         block_channel_sum<VEC>(q, red1, waves, wave, lane);
-        float rstd[VEC];
+        float rstd[VEC], shift[VEC];                  // shift: what the bias-free form adds to the centred x-hat
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) rstd[i] = 1.0f / sqrtf(q[i] * invC + 1e-5f);
+        for (int i = 0; i < VEC; ++i) {
+            rstd[i] = 1.0f / sqrtf(q[i] * invC + 1e-5f);
+            shift[i] = with_bias ? 0.f : mu[i] * rstd[i];
+        }
+#pragma unroll
+        for (int j = 0; j < CPT; ++j)
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) v[j][i] *= rstd[i];                 // centred x-hat
 
-        // parameter-gradient partials use dy itself; afterwards g <- dy * w
+        // pass 1 over dy: parameter-gradient sums and, per pixel, s1 = sum_c dy w, s2 = sum_c dy w xhat_c
         float s1[VEC], s2[VEC];
 #pragma unroll
         for (int i = 0; i < VEC; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) {
-            const int c = wave + j * waves;
-            if (c < C) {
-                const float w = weight[c];
+        for (int j0 = 0; j0 < CPT; j0 += GRP) {
+            float g[GRP][VEC];
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) {
-                    const float dyv = g[j][i];
-                    const float xh = with_bias ? (v[j][i] - mu[i]) * rstd[i] : v[j][i] * rstd[i];
-                    pw[j] += dyv * xh;
-                    pb[j] += dyv;
-                    const float gw = dyv * w;
-                    g[j][i] = gw;
-                    s1[i] += gw;
-                    s2[i] += with_bias ? gw * xh : gw * v[j][i];
+            for (int jj = 0; jj < GRP; ++jj) {
+                const int c = wave + (j0 + jj) * waves;
+                if (c < C) {
+                    buf_load<VEC>(g[jj], rdy, voff, (unsigned)c * plane);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) g[jj][i] = 0.f;
                 }
             }
+#pragma unroll
+            for (int jj = 0; jj < GRP; ++jj) {
+                const int j = j0 + jj;
+                const int c = wave + j * waves;
+                const float w = c < C ? weight[c] : 0.f;          // wave-uniform: a scalar load
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const float dyv = g[jj][i];
+                    pw[j] = fmaf(dyv, v[j][i] + shift[i], pw[j]);
+                    pb[j] += dyv;
+                    const float gw = dyv * w;
+                    s1[i] += gw;
+                    s2[i] = fmaf(gw, v[j][i], s2[i]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);        // the next group's loads stay behind this group's use
         }
         __syncthreads();   // red0/red1 are reused below
         block_channel_sum<VEC>(s1, red0, waves, wave, lane);
         block_channel_sum<VEC>(s2, red1, waves, wave, lane);
+        // with bias:  dx = rstd (dy w - s1/C - xhat_c s2/C)
+        // bias-free:  y = x rstd w, so dx = rstd dy w - rstd^3 (x - mu) (sum_c dy w x)/C with
+        //             sum_c dy w x = s2/rstd + mu s1  and  rstd^3 (x - mu) = rstd^2 xhat_c
+        float k1[VEC], k2[VEC];
 #pragma unroll
-        for (int j = 0; j < CPT; ++j) {
-            const int c = wave + j * waves;
-            if (c < C && pix_ok) {
-                float o[VEC];
+        for (int i = 0; i < VEC; ++i) {
+            if (with_bias) { k1[i] = s1[i] * invC; k2[i] = s2[i] * invC; }
+            else { k1[i] = 0.f; k2[i] = rstd[i] * (s2[i] / rstd[i] + mu[i] * s1[i]) * invC; }
+        }
+        // pass 2 over dy
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) {
-                    if (with_bias) {
-                        const float xh = (v[j][i] - mu[i]) * rstd[i];
-                        o[i] = rstd[i] * (g[j][i] - s1[i] * invC - xh * (s2[i] * invC));
-                    } else {
-                        const float r = rstd[i];
-                        o[i] = r * g[j][i] - r * r * r * (v[j][i] - mu[i]) * (s2[i] * invC);
-                    }
+        for (int j0 = 0; j0 < CPT; j0 += GRP) {
+            float g[GRP][VEC], old[GRP][VEC];
+#pragma unroll
+            for (int jj = 0; jj < GRP; ++jj) {
+                const int c = wave + (j0 + jj) * waves;
+                if (c < C) {
+                    buf_load<VEC>(g[jj], rdy, voff, (unsigned)c * plane);
+                    if (addend != nullptr) buf_load<VEC>(old[jj], radd, voff, (unsigned)c * plane);
                 }
-                float* dst = dx + base + (int64_t)c * N;
-                if (addend != nullptr) {
-                    float old[VEC];
-                    load_vec<VEC>(old, addend + base + (int64_t)c * N);
-#pragma unroll
-                    for (int i = 0; i < VEC; ++i) o[i] += old[i];
-                }
-                store_vec<VEC>(dst, o);
             }
+#pragma unroll
+            for (int jj = 0; jj < GRP; ++jj) {
+                const int j = j0 + jj;
+                const int c = wave + j * waves;
+                if (c < C) {
+                    const float w = weight[c];
+                    float o[VEC];
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        o[i] = rstd[i] * (g[jj][i] * w - k1[i] - v[j][i] * k2[i]);
+                        if (addend != nullptr) o[i] += old[jj][i];
+                    }
+                    buf_store<VEC>(o, rdx, pix_ok ? voff + (unsigned)c * plane : 0xFFFFFFF0u);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
@@ -300,7 +382,9 @@ static bool ln_plan(int C, int64_t N, bool ptr_aligned, bool backward, LnPlan* p
     }
     // backward holds x and dy: up to 16 waves (1024 threads -> 128 registers per lane), so two
     // blocks fit on a CU; the pixel vector shrinks as the channel share of a wave grows
-    int waves = (int)cdiv(C, 6);
+    // 49..96 channels: 12 channels per wave -> blocks of at most 8 waves, two or more of them per CU, out of
+    // phase (a block is a chain of load -> reduce -> load steps; a second one fills its waits)
+    int waves = (int)cdiv(C, (C > 48 && C <= 96) ? 12 : 6);
     if (waves > 16) waves = 16;
     const int cpt = (int)cdiv(C, waves);
     int want_vec;
@@ -313,7 +397,7 @@ static bool ln_plan(int C, int64_t N, bool ptr_aligned, bool backward, LnPlan* p
     return true;
 }
 
-static const int LN_BWD_MAX_BLOCKS = 512;
+static const int LN_BWD_MAX_BLOCKS = 1024;
 
 int layernorm_fwd_launch(const float* x, const float* weight, const float* bias, float* y,
                          int B, int C, int64_t N, hipStream_t stream) {
@@ -350,6 +434,7 @@ int layernorm_bwd_launch(const float* x, const float* weight, int with_bias, con
     if (ws == nullptr || ws_bytes < layernorm_bwd_ws_bytes(B, C, N))
         return fail(RST_ERR_WORKSPACE, "layernorm_bwd: workspace too small (%zu < %zu)", ws_bytes,
                     layernorm_bwd_ws_bytes(B, C, N));
+    RST_REQUIRE((int64_t)C * N * 4 < (1ll << 32) - 64, "layernorm_bwd: a sample of %d x %lld floats is beyond the 32-bit buffer offsets", C, (long long)N);
     const int64_t tps = cdiv(N, 64 * p.vec);
     const int64_t total = (int64_t)B * tps;
     const int grid = (int)(total < LN_BWD_MAX_BLOCKS ? total : LN_BWD_MAX_BLOCKS);
