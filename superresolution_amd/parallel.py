@@ -92,6 +92,7 @@ class DataParallelTrainer:
             for i, (p, v) in enumerate(zip(b.params, b.views)):
                 p.grad = v
                 self._owner[p] = (b, i)
+        self._host_staged = self.world > 1 and dev.type == "cuda" and dist.get_backend(process_group) == "gloo"
         if self.world > 1:
             for p in params:
                 p.register_post_accumulate_grad_hook(self._on_grad_ready)
@@ -100,8 +101,17 @@ class DataParallelTrainer:
     def broadcast_parameters(self):
         """Make every rank start from rank 0's parameters."""
         if self.world > 1:
-            for p in self.model.parameters():
-                dist.broadcast(p.data, src=0, group=self.group)
+            ps = list(self.model.parameters())
+            flat = torch.cat([p.data.reshape(-1) for p in ps])        # one message instead of one per tensor
+            # gloo (tests, ranks sharing a card) has no usable device broadcast: through the host there
+            host = flat.is_cuda and dist.get_backend(self.group) == "gloo"
+            buf = flat.cpu() if host else flat
+            dist.broadcast(buf, src=0, group=self.group)
+            flat = buf.to(flat.device) if host else buf
+            off = 0
+            for p in ps:
+                p.data.copy_(flat[off:off + p.numel()].view_as(p.data))
+                off += p.numel()
 
     def _on_grad_ready(self, p: nn.Parameter):
         b, i = self._owner[p]
@@ -111,7 +121,7 @@ class DataParallelTrainer:
             v.copy_(p.grad)
             p.grad = v
         b.pending -= 1
-        if b.pending == 0:
+        if b.pending == 0 and not self._host_staged:
             b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def zero_grad(self):
@@ -126,7 +136,15 @@ class DataParallelTrainer:
         out = self.model(x)
         loss = self.loss_fn(out, target)
         loss.backward()
-        if self.world > 1:
+        if self.world > 1 and self._host_staged:
+            # gloo with device buffers (tests: ranks sharing one card) -- large device collectives do not complete
+            # there, so the buckets go through the host, after the backward pass
+            for b in self.buckets:
+                tmp = b.flat.cpu()
+                dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
+                b.flat.copy_(tmp)
+                b.flat.div_(self.world)
+        elif self.world > 1:
             for b in self.buckets:
                 if b.handle is None:      # a parameter without gradient this step kept the bucket open
                     b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
