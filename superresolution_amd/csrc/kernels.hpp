@@ -56,6 +56,9 @@ struct PwDw {
 bool pwdw_supported(const PwDw& a);
 bool pwdw_profitable(const PwDw& a);      // supported and measured faster than the unfused pair
 int pwdw_launch(const PwDw& a, hipStream_t stream);
+// pwdw_ws.hip: the same operation with the MFMAs and the depthwise work in different waves (96 input channels, no gate)
+bool pwdw_ws_supported(const PwDw& a);
+int pwdw_ws_launch(const PwDw& a, hipStream_t stream);
 
 // ---- gemm_nt.hip ----
 struct GemmNT {

@@ -594,6 +594,7 @@ bool pwdw_supported(const PwDw& a) { return pwdw_plan(a).ok; }
 bool pwdw_profitable(const PwDw& a) { return pwdw_plan(a).ok; }
 
 int pwdw_launch(const PwDw& a, hipStream_t stream) {
+    if (pwdw_ws_supported(a)) return pwdw_ws_launch(a, stream);
     PwPlan p = pwdw_plan(a);
     RST_REQUIRE(p.ok, "pwdw: unsupported shape (K=%d W=%d)", a.K, a.W);
     RST_REQUIRE(a.X && a.A && a.dw_w && a.Y && a.B > 0 && a.M > 0, "pwdw: bad operand");
