@@ -1,0 +1,8 @@
+// Gated instantiation of the wave-specialised fused kernel (see pwdw_ws.hip for why it is a file of its own).
+#include "pwdw_ws_kernel.hpp"
+
+namespace rst {
+
+const void* pwdw_ws_gate_kernel() { return reinterpret_cast<const void*>(&pwdw_ws_kernel<24, 8, true>); }
+
+}  // namespace rst

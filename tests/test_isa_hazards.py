@@ -13,7 +13,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
-@pytest.mark.parametrize("src", ["pwdw.hip", "gemm_nn_res.hip"])
+@pytest.mark.parametrize("src", ["pwdw.hip", "pwdw_ws.hip", "pwdw_ws_gate.hip", "gemm_nn_res.hip"])
 def test_no_read_of_inflight_lds_result(src, tmp_path):
     import check_lds_inflight
     out = tmp_path / (src + ".s")

@@ -36,6 +36,9 @@ def check(text, name_filter=""):
                 continue
             t = l.strip()
             op = t.split()[0]
+            if op in ("s_endpgm", "s_branch", "s_setpc_b64"):
+                inflight = []             # straight-line flow ends here; what follows is reached from elsewhere
+                continue
             if op == "s_waitcnt":
                 m = re.search(r"lgkmcnt\((\d+)\)", t)
                 if m:
