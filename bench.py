@@ -107,9 +107,9 @@ def kernel_profile(run_once):
 
 def measured_traffic(name, batch, size, mode):
     """HBM bytes per launch of kernel group `name`, from the committed rocprofv3 --pmc run of this
-    same workload (profiles/r1_d_hbm_traffic.json; FETCH_SIZE and WRITE_SIZE collected in separate
+    same workload (profiles/r1_e_hbm_traffic.json; FETCH_SIZE and WRITE_SIZE collected in separate
     passes, FETCH_SIZE doubled as gfx950 requires).  None for any other workload or kernel."""
-    path = os.path.join(ROOT, "profiles", "r1_d_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r1_e_hbm_traffic.json")
     try:
         d = json.load(open(path))
     except (OSError, ValueError):

@@ -26,6 +26,8 @@ def group(name):
         return "gemm_nn_ln" if args[3] == "true" else "gemm_nn"
     if k == "pwdw_kernel":
         return "pwdw_gate" if args[2] == "true" else "pwdw"
+    if k == "pwdw_ws_kernel":
+        return "pwdw_gate" if args[2] == "true" else "pwdw"
     return {"gemm_nt_kernel": "gemm_nt_splitk", "dwconv_fwd_kernel": "dwconv3x3", "dwconv_gate_fwd_kernel": "dwconv3x3_gate",
             "pixel_shuffle2_kernel": "pixel_shuffle2+pixel_unshuffle2", "conv3x3_fewout_kernel": "conv3x3_fewout",
             "gemm_nn_kernel": "gemm_nn"}.get(k, k)
