@@ -7,13 +7,17 @@
 
 namespace rst {
 
-const void* pwdw_ws_gate_kernel();       // pwdw_ws_gate.hip
+const void* pwdw_ws_gate_kernel(int ks);       // pwdw_ws_gate.hip
 
 // ---- host side ----
 bool pwdw_ws_supported(const PwDw& a) {
     static const bool off = getenv("RST_PWDW_WS") != nullptr && getenv("RST_PWDW_WS")[0] == '0';
-    if (off || a.K != 96) return false;
-    if (a.gate ? a.M != 2 * a.hidden : a.M % 96 != 0) return false;  // plain: six slabs per block, no empty slab
+    if (off || (a.K != 96 && a.K != 48)) return false;
+    // 48 channels without gate: per row the vector waves have as much to do as at 96 channels and the matrix waves
+    // half -- 517 us against 390 us for the single-role kernel at 16 x 48 x 256^2 (the gated form still gains: 291 vs 313)
+    if (a.K == 48 && !a.gate) return false;
+    // plain: six (96 channels) or three (48) slabs per block, no empty slab; gated: four slab pairs per block
+    if (a.gate ? a.M != 2 * a.hidden : a.M % (a.K == 96 ? 96 : 48) != 0) return false;
     if (a.W % 4 != 0 || a.W < 64 || a.H < 2) return false;
     if (!aligned16(a.X) || a.x_bs % 4 != 0 || !aligned16(a.Y) || a.y_bs % 4 != 0) return false;
     if ((int64_t)a.K * a.H * a.W >= (1ll << 30)) return false;
@@ -24,19 +28,23 @@ int pwdw_ws_launch(const PwDw& a, hipStream_t stream) {
     RST_REQUIRE(pwdw_ws_supported(a), "pwdw_ws: unsupported shape (K=%d M=%d W=%d)", a.K, a.M, a.W);
     RST_REQUIRE(a.X && a.A && a.dw_w && a.Y && a.B > 0, "pwdw_ws: bad operand");
     RST_REQUIRE(a.ln_mode == 0 || (a.ln_s && a.ln_c), "pwdw_ws: folded LayerNorm without its constants");
-    constexpr int KS = 24;
-    const int NM = a.gate ? 8 : 6;
+    const int KS = a.K / 4;
+    const int NM = a.gate ? 8 : (a.K == 96 ? 6 : 3);
     const int nstrips = (int)cdiv(a.W, WS_WT), G = a.gate ? (int)cdiv(cdiv(a.hidden, 16), 4) : a.M / (16 * NM);
     int dev = 0, cus = 256;
     RST_HIP(hipGetDevice(&dev));
     RST_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    const void* kern = a.gate ? pwdw_ws_gate_kernel()
-                              : reinterpret_cast<const void*>(&pwdw_ws_kernel<KS, 6, false>);
-    const size_t lds = sizeof(float) * (size_t)(WS_STAGES * WS_XCH + 256 + 4 * WS_ROWF + NM * WS_T * 256 + NM * 2 * 64 + NM * KS * 64);
+    const void* kern = a.gate ? pwdw_ws_gate_kernel(KS)
+                     : KS == 24 ? reinterpret_cast<const void*>(&pwdw_ws_kernel<24, 6, false>)
+                                : reinterpret_cast<const void*>(&pwdw_ws_kernel<12, 3, false>);
+    const size_t lds = sizeof(float) * (size_t)(WS_STAGES * ws_xch(KS) + 256 + 4 * WS_ROWF + NM * WS_T * 256 + NM * 2 * 64 + NM * KS * 64);
     RST_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 1;
+    RST_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, NM * 128, lds));
+    if (per_cu < 1) per_cu = 1;
     // rows of every (sample, strip, channel group) column split so that the grid comes in whole rounds of
     // resident blocks (one per CU); every row range recomputes two halo rows
-    const int64_t cols0 = (int64_t)a.B * nstrips, slots = cus;
+    const int64_t cols0 = (int64_t)a.B * nstrips, slots = (int64_t)cus * per_cu;
     int nsplit = 1;
     double best = -1.0;
     for (int ns = 1; ns <= (a.H >= 16 ? a.H / 8 : 1); ++ns) {

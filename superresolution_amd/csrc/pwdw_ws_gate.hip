@@ -3,6 +3,9 @@
 
 namespace rst {
 
-const void* pwdw_ws_gate_kernel() { return reinterpret_cast<const void*>(&pwdw_ws_kernel<24, 8, true>); }
+const void* pwdw_ws_gate_kernel(int ks) {
+    return ks == 24 ? reinterpret_cast<const void*>(&pwdw_ws_kernel<24, 8, true>)
+                    : reinterpret_cast<const void*>(&pwdw_ws_kernel<12, 8, true>);
+}
 
 }  // namespace rst

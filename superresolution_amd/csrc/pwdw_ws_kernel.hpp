@@ -37,10 +37,10 @@ constexpr int WS_WT = 16 * WS_T;         // strip width
 constexpr int WS_CPR = 20;               // 16-byte pieces per channel row in LDS (4 px halo + 64 + 4 px halo, padded)
 constexpr int WS_ROWF = WS_CPR * 4;      // == 16 (mod 64): the four k-rows of an operand read hit disjoint banks
 constexpr int WS_NSG = WS_ROWF / 16;     // groups of 16 ring columns for the statistics
-constexpr int WS_CK = 48;                // channels per ring stage
 constexpr int WS_STAGES = 4;
-constexpr int WS_NINSTR = (WS_CK * WS_CPR + 63) / 64;     // wave-wide DMA instructions per chunk
-constexpr int WS_XCH = WS_NINSTR * 256;                    // floats per ring stage
+constexpr int ws_ck(int ks) { return ks >= 24 ? 48 : 24; }                    // channels per ring stage (two stages per row at least)
+constexpr int ws_ninstr(int ks) { return (ws_ck(ks) * WS_CPR + 63) / 64; }     // wave-wide DMA instructions per chunk
+constexpr int ws_xch(int ks) { return ws_ninstr(ks) * 256; }                   // floats per ring stage
 
 // gelu(x) = x * Phi(x) without a branch: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 on erf, measured
 // <= 4.3e-7 absolute on gelu over [-8, 8] in fp32), one reciprocal and one exponential.  The library erff has two
@@ -69,6 +69,7 @@ __device__ __forceinline__ void ws_static_for(F&& f) {
 template <int KS, int NM, bool GATE>
 __global__ void __launch_bounds__(NM * 128) __attribute__((amdgpu_waves_per_eu(GATE ? 4 : 3, GATE ? 4 : 3)))
 pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
+    constexpr int WS_CK = ws_ck(KS), WS_NINSTR = ws_ninstr(KS), WS_XCH = ws_xch(KS);
     constexpr int T = WS_T, WT = WS_WT, ROWF = WS_ROWF, XCH = WS_XCH;
     constexpr int ND = NM;                               // vector waves
     constexpr int PAIRS = NM / 2;                        // GATE: slab pairs per block
@@ -314,9 +315,10 @@ pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
             issue();
             const float* Xs = ring + stage_c * XCH;
             // this wave's ring columns for the LayerNorm statistics: read now, summed at the end of the phase
-            float sx[NTW][GATE ? 1 : CKS];
+            constexpr bool SAHEAD = !GATE && KS >= 24;      // statistics columns read ahead of their use (costs NTW * CKS registers)
+            float sx[NTW][SAHEAD ? CKS : 1];
             const bool do_stats = have_row && a.ln_mode != 0;
-            if (!GATE && do_stats) {
+            if (SAHEAD && do_stats) {
 #pragma unroll
                 for (int jj = 0; jj < NTW; ++jj) {
                     const int sg = dwave + jj * ND < WS_NSG ? dwave + jj * ND : WS_NSG - 1;
@@ -395,8 +397,8 @@ pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
                     const int sg = dwave + jj * ND < WS_NSG ? dwave + jj * ND : WS_NSG - 1;
 #pragma unroll
                     for (int s = 0; s < CKS; ++s) {
-                        // (the 16-wave gated form has 128 registers per lane: it reads here instead of ahead)
-                        const float x = GATE ? Xs[(4 * s + kk) * ROWF + 16 * sg + lm] : sx[jj][s];
+                        // (the forms that are short of registers read here instead of ahead)
+                        const float x = SAHEAD ? sx[jj][s] : Xs[(4 * s + kk) * ROWF + 16 * sg + lm];
                         st[jj][0] += x;
                         st[jj][1] = fmaf(x, x, st[jj][1]);
                     }
