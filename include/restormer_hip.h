@@ -248,6 +248,37 @@ int rst_block_shard_fwd_apply(const rst_block_desc* desc, const rst_block_params
                               void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* bf16 storage path (inference).  The reference runs this path in whatever    */
+/* dtype the module was cast to (model/train.py:72 casts to fp32; autocast or   */
+/* .bfloat16() give bf16 tensors between its torch operators).  Here the        */
+/* activations between kernels are bf16 and every sum is fp32; parameters stay  */
+/* fp32 device arrays as in rst_block_params.                                   */
+/* Activation layout: "channel-packed" bf16, [B][ceil(C/8)][N][8] -- the 8       */
+/* channels of a block for one pixel form one 16-byte chunk (channels beyond C   */
+/* are zero).  rst_bf16_pack / rst_bf16_unpack convert from / to planar NCHW     */
+/* (fp32 or bf16).  N = H*W must be even; C a multiple of 8 for the block.       */
+/* ------------------------------------------------------------------------- */
+size_t rst_bf16_packed_bytes(int32_t B, int32_t C, int64_t N);
+int rst_bf16_pack(const void* x, int32_t x_is_fp32, void* y_packed,
+                  int32_t B, int32_t C, int64_t N, void* stream);
+int rst_bf16_unpack(const void* x_packed, void* y, int32_t y_is_fp32,
+                    int32_t B, int32_t C, int64_t N, void* stream);
+/* nn.Conv2d(Cin, Cout, kernel_size=1) on packed tensors (+ packed residual),     */
+/* model/Restromer.py:309-311,326-328.  Cin <= 480.  y may alias residual.        */
+size_t rst_bf16_conv1x1_workspace_bytes(int32_t Cin, int32_t Cout);
+int rst_bf16_conv1x1_fwd(const void* x_packed, const float* weight, const float* bias,
+                         const void* residual_packed, void* y_packed,
+                         int32_t B, int32_t Cin, int32_t Cout, int64_t N,
+                         void* workspace, size_t workspace_bytes, void* stream);
+/* TransformerBlock.forward, model/Restromer.py:163-167, on a packed tensor;      */
+/* y may alias x.  C % 8 == 0, C / heads a multiple of 16 (<= 192), C and hidden  */
+/* at most 480.  Returns 0 bytes / RST_ERR_INVALID for unsupported shapes.        */
+size_t rst_bf16_block_workspace_bytes(const rst_block_desc* desc);
+int rst_bf16_block_fwd(const rst_block_desc* desc, const rst_block_params* params,
+                       const void* x_packed, void* y_packed,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* Per-kernel timing aid.  No counterpart in the reference (it has no timing   */
 /* code on this path); used by bench.py for the roofline numbers.  Between     */
 /* begin and end every kernel launch of this library is bracketed by HIP       */

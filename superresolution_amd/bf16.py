@@ -1,0 +1,112 @@
+"""bf16 storage path (inference): host side of the rst_bf16_* entry points.
+
+Between kernels the activations are bf16 in the channel-packed layout of the
+library, a torch tensor of shape (B, ceil(C/8), H, W, 8): the 8 channels of a
+block for one pixel are one 16-byte chunk, which is what the matrix
+instructions consume directly.  Parameters stay fp32; every sum is fp32.
+torch supplies memory and the stream only; a CPU tensor raises RuntimeError.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from ._lib import BlockParams, PARAM_FIELDS, check
+from .ops import _fill, _ptr, _stream, make_desc, workspace
+
+
+class Packed:
+    """A (B, C, H, W) activation in the packed bf16 layout."""
+    __slots__ = ("data", "C")
+
+    def __init__(self, data: torch.Tensor, C: int):
+        if data.dtype != torch.bfloat16 or data.dim() != 5 or data.shape[-1] != 8 or not data.is_contiguous():
+            raise RuntimeError("Packed needs a contiguous bf16 tensor of shape (B, ceil(C/8), H, W, 8)")
+        if not data.is_cuda:
+            raise RuntimeError("Packed tensors live on a ROCm GPU (there is no CPU fallback)")
+        self.data, self.C = data, int(C)
+
+    @property
+    def shape(self):
+        b, cb, h, w, _ = self.data.shape
+        return (b, self.C, h, w)
+
+
+def _f32(p: Optional[torch.Tensor], name: str) -> Optional[torch.Tensor]:
+    if p is None:
+        return None
+    if not p.is_cuda:
+        raise RuntimeError(f"{name}: parameter is on {p.device}; the bf16 path only runs on a ROCm GPU")
+    return p.detach().float().contiguous()
+
+
+def pack(x: torch.Tensor) -> Packed:
+    """NCHW fp32 or bf16 -> packed bf16 (round to nearest even)."""
+    lib = _lib.load()
+    if not x.is_cuda:
+        raise RuntimeError(f"pack: tensor is on {x.device}; this operator only runs on a ROCm GPU")
+    if x.dtype not in (torch.float32, torch.bfloat16) or x.dim() != 4:
+        raise RuntimeError(f"pack: expected a 4-D fp32 or bf16 tensor, got {x.dtype} {tuple(x.shape)}")
+    x = x.contiguous()
+    B, C, H, W = x.shape
+    out = torch.empty((B, (C + 7) // 8, H, W, 8), dtype=torch.bfloat16, device=x.device)
+    check(lib.rst_bf16_pack(_ptr(x), int(x.dtype == torch.float32), _ptr(out), B, C, H * W, _stream()), "rst_bf16_pack")
+    return Packed(out, C)
+
+
+def unpack(p: Packed, dtype=torch.bfloat16) -> torch.Tensor:
+    """packed bf16 -> NCHW fp32 or bf16."""
+    lib = _lib.load()
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError(f"unpack: dtype {dtype} not supported")
+    B, C, H, W = p.shape
+    out = torch.empty((B, C, H, W), dtype=dtype, device=p.data.device)
+    check(lib.rst_bf16_unpack(_ptr(p.data), _ptr(out), int(dtype == torch.float32), B, C, H * W, _stream()), "rst_bf16_unpack")
+    return out
+
+
+def conv1x1(p: Packed, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[Packed] = None) -> Packed:
+    """nn.Conv2d(kernel_size=1) on a packed tensor (reference: model/Restromer.py:309-311,326-328)."""
+    lib = _lib.load()
+    B, Cin, H, W = p.shape
+    w = _f32(weight, "conv1x1 weight")
+    Cout = w.shape[0]
+    if w.numel() != Cout * Cin:
+        raise RuntimeError(f"conv1x1: weight {tuple(weight.shape)} does not match {Cin} input channels")
+    b = _f32(bias, "conv1x1 bias")
+    nb = lib.rst_bf16_conv1x1_workspace_bytes(Cin, Cout)
+    if nb == 0:
+        raise RuntimeError(f"conv1x1: {Cin} input channels not supported by the bf16 path")
+    ws = workspace(nb, p.data.device)
+    out = torch.empty((B, (Cout + 7) // 8, H, W, 8), dtype=torch.bfloat16, device=p.data.device)
+    if residual is not None and residual.shape != (B, Cout, H, W):
+        raise RuntimeError("conv1x1: residual shape mismatch")
+    check(lib.rst_bf16_conv1x1_fwd(_ptr(p.data), _ptr(w), _ptr(b), None if residual is None else _ptr(residual.data), _ptr(out),
+                                   B, Cin, Cout, H * W, _ptr(ws), ws.numel(), _stream()), "rst_bf16_conv1x1_fwd")
+    return Packed(out, Cout)
+
+
+def block_(p: Packed, heads: int, hidden: int, params: Dict[str, Optional[torch.Tensor]]) -> Packed:
+    """TransformerBlock (reference: model/Restromer.py:163-167) applied in place to a packed tensor."""
+    lib = _lib.load()
+    B, C, H, W = p.shape
+    tensors = {n: _f32(params.get(n), n) for n in PARAM_FIELDS}
+    desc = make_desc(B, C, H, W, heads, hidden, tensors["norm1_bias"] is not None, tensors["qkv_bias"] is not None)
+    nb = lib.rst_bf16_block_workspace_bytes(ctypes.byref(desc))
+    if nb == 0:
+        raise RuntimeError("bf16 block: " + lib.rst_last_error().decode("utf-8", "replace"))
+    par = _fill(BlockParams(), tensors)
+    ws = workspace(nb, p.data.device)
+    check(lib.rst_bf16_block_fwd(ctypes.byref(desc), ctypes.byref(par), _ptr(p.data), _ptr(p.data), _ptr(ws), ws.numel(),
+                                 _stream()), "rst_bf16_block_fwd")
+    return p
+
+
+def cat(a: Packed, b: Packed) -> Packed:
+    """torch.cat([a, b], 1) (reference: model/Restromer.py:402,407,412); needs a.C % 8 == 0."""
+    if a.C % 8:
+        raise RuntimeError("cat: the first tensor's channel count must be a multiple of 8 in the packed layout")
+    return Packed(torch.cat([a.data, b.data], 1), a.C + b.C)

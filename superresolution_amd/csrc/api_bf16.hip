@@ -1,0 +1,269 @@
+// C ABI of the bf16 storage path (inference): channel-packed bf16 activations, fp32 parameters and sums.
+// Launch sequences only; the kernels are in bf16_pk.hip and attn_small.hip.
+#include "kernels.hpp"
+
+namespace rst {
+
+namespace {
+
+struct Carve {
+    char* base; size_t off = 0;
+    explicit Carve(void* b) : base(static_cast<char*>(b)) {}
+    void* bytes(size_t n) {
+        off = (off + 255) & ~size_t(255);
+        void* p = base ? static_cast<void*>(base + off) : nullptr;
+        off += n;
+        return p;
+    }
+    float* floats(size_t n) { return static_cast<float*>(bytes(n * sizeof(float))); }
+    bf16_t* halves(size_t n) { return static_cast<bf16_t*>(bytes(n * sizeof(bf16_t))); }
+    size_t total() const { return (off + 255) & ~size_t(255); }
+};
+
+inline int pad8(int c) { return (int)round_up(c, 8); }
+constexpr int NOSEG = 1 << 30;          // "one segment": the source channels map to the positions one to one
+
+// prepared form of one 1x1 weight matrix: operand fragments + per-position constants
+struct PkWeight {
+    int K, M, seg, seg_pad;      // source [M][K]; output positions in segments
+    int Kb, Mb, KS, P, ngroups, ntiles, npos;
+    bf16_t* frag; float* s; float* c;
+    size_t frag_elems() const { return (size_t)ntiles * KS * 64 * 8; }
+};
+PkWeight pk_weight_shape(int M, int K, int seg, int seg_pad) {
+    PkWeight w{};
+    w.K = K; w.M = M; w.seg = seg; w.seg_pad = seg_pad;
+    const int nseg = (int)cdiv(M, seg);
+    w.Kb = (int)cdiv(K, 8);
+    w.Mb = seg_pad >= NOSEG ? (int)cdiv(M, 8) : nseg * seg_pad / 8;
+    w.KS = gemm_pk_ks(w.Kb);
+    w.P = gemm_pk_pairs(w.Kb, w.Mb);
+    w.ngroups = (int)cdiv(cdiv(w.Mb, 4), w.P);
+    w.ntiles = w.ngroups * w.P * 2;
+    w.npos = w.ngroups * w.P * 32;
+    return w;
+}
+void pk_weight_carve(PkWeight& w, Carve& cv, int nb) {
+    w.frag = cv.halves(w.frag_elems() * nb);
+    w.s = cv.floats(w.npos);
+    w.c = cv.floats(w.npos);
+}
+// weights shared by the samples; gamma/beta: LayerNorm folded in front; bias: of the convolution
+int pk_weight_prepare(const PkWeight& w, const float* src, const float* gamma, const float* beta, const float* bias,
+                      hipStream_t stream) {
+    RST_TRY(pk_prep_a_launch(src, 0, w.K, gamma, w.M, w.K, w.seg, w.seg_pad, w.ntiles, w.KS, w.frag, 0, 1, stream));
+    return pk_prep_sc_launch(src, w.K, gamma, beta, bias, w.M, w.K, w.seg, w.seg_pad, w.npos, w.s, w.c, stream);
+}
+
+int check_pk_desc(const rst_block_desc* d) {
+    RST_REQUIRE(d != nullptr, "null block descriptor");
+    RST_REQUIRE(d->B > 0 && d->C > 0 && d->H > 0 && d->W > 0, "bf16 block: empty shape B=%d C=%d H=%d W=%d", d->B, d->C, d->H, d->W);
+    RST_REQUIRE(d->heads > 0 && d->C % d->heads == 0, "bf16 block: C=%d not divisible by heads=%d", d->C, d->heads);
+    RST_REQUIRE(d->hidden > 0, "bf16 block: hidden=%d", d->hidden);
+    RST_REQUIRE(d->C % 8 == 0, "bf16 block: C=%d must be a multiple of 8", d->C);
+    RST_REQUIRE(gram_pk_supported(d->C / d->heads), "bf16 block: %d channels per head not supported (multiples of 16 up to 192)", d->C / d->heads);
+    RST_REQUIRE(((int64_t)d->H * d->W) % 2 == 0, "bf16 block: H*W must be even");
+    RST_REQUIRE(gemm_pk_ks(d->C / 8) > 0 && gemm_pk_ks(pad8(d->hidden) / 8) > 0, "bf16 block: C=%d / hidden=%d too wide (at most 480 input channels per product)", d->C, d->hidden);
+    return RST_OK;
+}
+
+struct PkBlockBufs {
+    PkWeight wqkv, wattn, wpin, wpout;
+    float *dw_qkv, *dw_ffn;
+    bf16_t *buf1, *buf2;              // t / u   and   qkv / g
+    float *gram_part, *sqq_part, *sqk_part, *gram_red, *sqq_red, *sqk_red, *attn, *mfold;
+    int splits; int64_t chunk;
+};
+
+GemmPk pk_gemm_args(const PkWeight& w, const bf16_t* x, int64_t x_bs, bf16_t* y, int64_t y_bs, int B, int64_t N) {
+    GemmPk g{};
+    g.A = w.frag; g.a_bs = 0;
+    g.X = x; g.x_bs = x_bs; g.Y = y; g.y_bs = y_bs; g.R = nullptr; g.r_bs = 0;
+    g.ln_s = nullptr; g.ln_c = nullptr; g.ln_mode = 0;
+    g.K = w.K; g.Kb = w.Kb; g.Mb = w.Mb; g.B = B; g.N = N;
+    return g;
+}
+
+}  // namespace
+
+static PkWeight pk_plain_weight(int M, int K) { return pk_weight_shape(M, K, NOSEG, NOSEG); }
+
+static void pk_block_carve(const rst_block_desc* d, Carve& cv, PkBlockBufs& b);
+
+static size_t pk_block_ws_bytes(const rst_block_desc* d) {
+    Carve cv(nullptr); PkBlockBufs b{};
+    pk_block_carve(d, cv, b);
+    return cv.total();
+}
+
+static void pk_block_carve(const rst_block_desc* d, Carve& cv, PkBlockBufs& b) {
+    const int C = d->C, Hd = d->hidden, Hp = pad8(Hd), heads = d->heads, c = C / heads, B = d->B;
+    const int64_t N = (int64_t)d->H * d->W;
+    b.wqkv = pk_plain_weight(3 * C, C);
+    b.wattn = pk_plain_weight(C, C);
+    b.wpin = pk_weight_shape(2 * Hd, C, Hd, Hp);
+    b.wpout = pk_plain_weight(C, Hd);
+    pk_weight_carve(b.wqkv, cv, 1);
+    pk_weight_carve(b.wattn, cv, B);
+    pk_weight_carve(b.wpin, cv, 1);
+    pk_weight_carve(b.wpout, cv, 1);
+    b.dw_qkv = cv.floats((size_t)(3 * C / 8) * 80);
+    b.dw_ffn = cv.floats((size_t)(2 * Hp / 8) * 80);
+    const int w1 = 3 * C > 2 * Hp ? 3 * C : 2 * Hp, w2 = 3 * C > Hp ? 3 * C : Hp;
+    b.buf1 = cv.halves((size_t)B * w1 * N);
+    b.buf2 = cv.halves((size_t)B * w2 * N);
+    gram_pk_plan(c, N, B * heads, &b.splits, &b.chunk);
+    const size_t BH = (size_t)B * heads;
+    b.gram_part = cv.floats(BH * b.splits * c * c);
+    b.sqq_part = cv.floats(BH * b.splits * c);
+    b.sqk_part = cv.floats(BH * b.splits * c);
+    b.gram_red = cv.floats(BH * c * c);
+    b.sqq_red = cv.floats(BH * c);
+    b.sqk_red = cv.floats(BH * c);
+    b.attn = cv.floats(BH * c * c);
+    b.mfold = cv.floats((size_t)B * C * C);
+}
+
+// x1 = x + attention(LN1(x));  y = x1 + ffn(LN2(x1))   (model/Restromer.py:163-167), y may alias x
+static int pk_block_fwd(const rst_block_desc* d, const rst_block_params* p, const bf16_t* x, bf16_t* y,
+                        void* ws, size_t ws_bytes, hipStream_t stream) {
+    RST_REQUIRE(x && y && p, "bf16 block: null operand");
+    RST_REQUIRE(p->norm1_weight && p->norm2_weight, "bf16 block: null LayerNorm weight");
+    RST_REQUIRE(!d->ln_with_bias || (p->norm1_bias && p->norm2_bias), "bf16 block: ln_with_bias set but a bias is null");
+    RST_REQUIRE(p->temperature && p->qkv_weight && p->qkv_dw_weight && p->proj_weight, "bf16 block: null attention parameter");
+    RST_REQUIRE(p->pin_weight && p->ffn_dw_weight && p->pout_weight, "bf16 block: null feed-forward parameter");
+    RST_REQUIRE(!d->conv_bias || (p->qkv_bias && p->qkv_dw_bias && p->proj_bias && p->pin_bias && p->ffn_dw_bias && p->pout_bias),
+                "bf16 block: conv_bias set but a bias is null");
+    if (ws == nullptr || ws_bytes < pk_block_ws_bytes(d))
+        return fail(RST_ERR_WORKSPACE, "bf16 block: workspace %zu < %zu bytes", ws_bytes, pk_block_ws_bytes(d));
+    const int C = d->C, Hd = d->hidden, Hp = pad8(Hd), heads = d->heads, c = C / heads, B = d->B;
+    const int64_t N = (int64_t)d->H * d->W;
+    const int big = NOSEG;
+    const bool cb = d->conv_bias != 0;
+    const int ln_mode = d->ln_with_bias ? 1 : 2;
+    Carve cv(ws); PkBlockBufs b{};
+    pk_block_carve(d, cv, b);
+    bf16_t* t = b.buf1; bf16_t* qkv = b.buf2; bf16_t* u = b.buf1; bf16_t* gbuf = b.buf2;
+    const int64_t cn = (int64_t)C * N;
+
+    // ---- MDTA (model/Restromer.py:128-150) ----
+    RST_TRY(pk_weight_prepare(b.wqkv, p->qkv_weight, p->norm1_weight, d->ln_with_bias ? p->norm1_bias : nullptr,
+                              cb ? p->qkv_bias : nullptr, stream));
+    {
+        GemmPk g = pk_gemm_args(b.wqkv, x, cn, t, 3 * cn, B, N);
+        g.ln_mode = ln_mode; g.ln_s = b.wqkv.s; g.ln_c = b.wqkv.c;
+        RST_TRY(gemm_pk_launch(g, stream));
+    }
+    RST_TRY(pk_prep_dw_launch(p->qkv_dw_weight, cb ? p->qkv_dw_bias : nullptr, 3 * C, big, big, 3 * C / 8, b.dw_qkv, stream));
+    {
+        DwPk a{};
+        a.x = t; a.x_bs = 3 * cn; a.wp = b.dw_qkv; a.y = qkv; a.y_bs = 3 * cn;
+        a.B = B; a.Cb_out = 3 * C / 8; a.H = d->H; a.W = d->W; a.gate_off = 0;
+        RST_TRY(dw_pk_launch(a, stream));
+    }
+    {
+        GramPk g{};
+        g.Q = qkv; g.Kx = qkv + cn; g.bs = 3 * cn; g.cb = c / 8; g.heads = heads; g.B = B; g.N = N;
+        g.splits = b.splits; g.chunk_px = b.chunk; g.partial = b.gram_part; g.sqq = b.sqq_part; g.sqk = b.sqk_part;
+        RST_TRY(gram_pk_launch(g, stream));
+    }
+    if (b.splits > 16) {
+        RST_TRY(reduce_slabs_launch(b.gram_part, b.gram_red, (int64_t)c * c, B * heads, b.splits, 0, stream));
+        RST_TRY(reduce_slabs_launch(b.sqq_part, b.sqq_red, c, B * heads, b.splits, 0, stream));
+        RST_TRY(reduce_slabs_launch(b.sqk_part, b.sqk_red, c, B * heads, b.splits, 0, stream));
+        RST_TRY(attn_softmax_launch(b.gram_red, b.sqq_red, b.sqk_red, p->temperature, b.attn, nullptr, nullptr, nullptr,
+                                    B, heads, c, 1, stream));
+    } else {
+        RST_TRY(attn_softmax_launch(b.gram_part, b.sqq_part, b.sqk_part, p->temperature, b.attn, nullptr, nullptr, nullptr,
+                                    B, heads, c, b.splits, stream));
+    }
+    RST_TRY(attn_fold_launch(p->proj_weight, b.attn, b.mfold, B, C, heads, c, stream));
+    RST_TRY(pk_prep_a_launch(b.mfold, (int64_t)C * C, C, nullptr, C, C, big, big, b.wattn.ntiles, b.wattn.KS, b.wattn.frag,
+                             (int64_t)b.wattn.frag_elems(), B, stream));
+    if (cb) RST_TRY(pk_prep_sc_launch(p->proj_weight, C, nullptr, nullptr, p->proj_bias, C, C, big, big, b.wattn.npos,
+                                      b.wattn.s, b.wattn.c, stream));
+    {
+        GemmPk g = pk_gemm_args(b.wattn, qkv + 2 * cn, 3 * cn, y, cn, B, N);
+        g.a_bs = (int64_t)b.wattn.frag_elems() / 8;
+        g.R = x; g.r_bs = cn;
+        g.ln_c = cb ? b.wattn.c : nullptr;
+        RST_TRY(gemm_pk_launch(g, stream));
+    }
+    // ---- GDFN (model/Restromer.py:99-104) ----
+    RST_TRY(pk_weight_prepare(b.wpin, p->pin_weight, p->norm2_weight, d->ln_with_bias ? p->norm2_bias : nullptr,
+                              cb ? p->pin_bias : nullptr, stream));
+    {
+        GemmPk g = pk_gemm_args(b.wpin, y, cn, u, (int64_t)2 * Hp * N, B, N);
+        g.ln_mode = ln_mode; g.ln_s = b.wpin.s; g.ln_c = b.wpin.c;
+        RST_TRY(gemm_pk_launch(g, stream));
+    }
+    RST_TRY(pk_prep_dw_launch(p->ffn_dw_weight, cb ? p->ffn_dw_bias : nullptr, 2 * Hd, Hd, Hp, 2 * Hp / 8, b.dw_ffn, stream));
+    {
+        DwPk a{};
+        a.x = u; a.x_bs = (int64_t)2 * Hp * N; a.wp = b.dw_ffn; a.y = gbuf; a.y_bs = (int64_t)Hp * N;
+        a.B = B; a.Cb_out = Hp / 8; a.H = d->H; a.W = d->W; a.gate_off = Hp / 8;
+        RST_TRY(dw_pk_launch(a, stream));
+    }
+    RST_TRY(pk_weight_prepare(b.wpout, p->pout_weight, nullptr, nullptr, cb ? p->pout_bias : nullptr, stream));
+    {
+        GemmPk g = pk_gemm_args(b.wpout, gbuf, (int64_t)Hp * N, y, cn, B, N);
+        g.R = y; g.r_bs = cn;
+        g.ln_c = cb ? b.wpout.c : nullptr;
+        RST_TRY(gemm_pk_launch(g, stream));
+    }
+    return RST_OK;
+}
+
+}  // namespace rst
+
+using namespace rst;
+
+extern "C" {
+
+size_t rst_bf16_packed_bytes(int32_t B, int32_t C, int64_t N) {
+    if (B <= 0 || C <= 0 || N <= 0) return 0;
+    return (size_t)B * (size_t)round_up(C, 8) * (size_t)N * sizeof(bf16_t);
+}
+int rst_bf16_pack(const void* x, int32_t x_is_fp32, void* y_packed, int32_t B, int32_t C, int64_t N, void* stream) {
+    return pk_pack_launch(x, x_is_fp32, static_cast<bf16_t*>(y_packed), B, C, N, static_cast<hipStream_t>(stream));
+}
+int rst_bf16_unpack(const void* x_packed, void* y, int32_t y_is_fp32, int32_t B, int32_t C, int64_t N, void* stream) {
+    return pk_unpack_launch(static_cast<const bf16_t*>(x_packed), y, y_is_fp32, B, C, N, static_cast<hipStream_t>(stream));
+}
+
+size_t rst_bf16_conv1x1_workspace_bytes(int32_t Cin, int32_t Cout) {
+    if (Cin <= 0 || Cout <= 0 || gemm_pk_ks((int)cdiv(Cin, 8)) < 0) return 0;
+    PkWeight w = pk_plain_weight(Cout, Cin);
+    Carve cv(nullptr);
+    pk_weight_carve(w, cv, 1);
+    return cv.total();
+}
+int rst_bf16_conv1x1_fwd(const void* x_packed, const float* weight, const float* bias, const void* residual_packed,
+                         void* y_packed, int32_t B, int32_t Cin, int32_t Cout, int64_t N,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+    RST_REQUIRE(x_packed && weight && y_packed, "bf16 conv1x1: null operand");
+    RST_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && N > 0, "bf16 conv1x1: empty shape");
+    RST_REQUIRE(gemm_pk_ks((int)cdiv(Cin, 8)) > 0, "bf16 conv1x1: %d input channels not supported (at most 480)", Cin);
+    if (workspace == nullptr || workspace_bytes < rst_bf16_conv1x1_workspace_bytes(Cin, Cout))
+        return fail(RST_ERR_WORKSPACE, "bf16 conv1x1: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    PkWeight w = pk_plain_weight(Cout, Cin);
+    Carve cv(workspace);
+    pk_weight_carve(w, cv, 1);
+    RST_TRY(pk_weight_prepare(w, weight, nullptr, nullptr, bias, st));
+    const int64_t xs = (int64_t)round_up(Cin, 8) * N, ys = (int64_t)round_up(Cout, 8) * N;
+    GemmPk g = pk_gemm_args(w, static_cast<const bf16_t*>(x_packed), xs, static_cast<bf16_t*>(y_packed), ys, B, N);
+    g.R = static_cast<const bf16_t*>(residual_packed); g.r_bs = ys;
+    g.ln_c = bias ? w.c : nullptr;
+    return gemm_pk_launch(g, st);
+}
+
+size_t rst_bf16_block_workspace_bytes(const rst_block_desc* d) { return check_pk_desc(d) == RST_OK ? pk_block_ws_bytes(d) : 0; }
+int rst_bf16_block_fwd(const rst_block_desc* d, const rst_block_params* p, const void* x_packed, void* y_packed,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+    RST_TRY(check_pk_desc(d));
+    return pk_block_fwd(d, p, static_cast<const bf16_t*>(x_packed), static_cast<bf16_t*>(y_packed), workspace, workspace_bytes,
+                        static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

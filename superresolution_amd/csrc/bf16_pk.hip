@@ -1,0 +1,651 @@
+// bf16 storage path (inference): activations are bf16 in memory, every sum is fp32.
+//
+// Layout.  Activations are "channel-packed": [B][Cb][H*W][8] with Cb = ceil(C/8); the 8 channels of a
+// block sit in one 16-byte chunk per pixel.  That chunk is exactly the B operand of
+// v_mfma_f32_16x16x32_bf16 (lane (n, g) holds 8 consecutive k of pixel n), so a 1x1 convolution reads
+// its operand straight from memory into the matrix pipe: no LDS staging and no transposition.  The
+// rows of the weight matrix are permuted when the weights are prepared so that the 4 + 4 accumulator
+// rows a lane holds for two 16-row tiles are 8 consecutive channels: the result leaves as one 16-byte
+// chunk per lane in the same packed layout.  The depthwise 3x3 reads and writes 16-byte chunks per
+// pixel, and the Gram product q k^T over the pixels transposes its operands on the way out of LDS with
+// ds_read_b64_tr_b16.
+#include "kernels.hpp"
+
+namespace rst {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {     // round to nearest even
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ void unpack8(const u32x4 w, float* v) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = bf_lo(w[i]); v[2 * i + 1] = bf_hi(w[i]); }
+}
+__device__ __forceinline__ u32x4 pack8(const float* v) {
+    u32x4 w;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = pack_bf16(v[2 * i], v[2 * i + 1]);
+    return w;
+}
+__device__ __forceinline__ uint16_t to_bf16_bits(float x) { return (uint16_t)(pack_bf16(x, 0.f) & 0xffffu); }
+
+// Position p of a packed buffer -> channel of the source tensor, or -1 for padding.  The source channels come in
+// segments of `seg` channels, each padded to `seg_pad` positions (the two halves of the gated feed-forward).
+__device__ __forceinline__ int src_channel(int p, int seg, int seg_pad, int total) {
+    const int q = p / seg_pad, r = p % seg_pad;
+    const int ch = q * seg + r;
+    return (r < seg && ch < total) ? ch : -1;
+}
+
+// ---- weight preparation -----------------------------------------------------------------------------------
+// frag[b][mt][ks][lane][j] = A operand of m-tile mt, k-step ks:  row = permuted position, k = 32 ks + 8 (lane>>4) + j
+// position of (mt, rr = lane & 15): 32 (mt>>1) + 8 (rr>>2) + 4 (mt&1) + (rr&3)
+__global__ void __launch_bounds__(256)
+pk_prep_a_kernel(const float* __restrict__ w, int64_t w_bs, int ldw, const float* __restrict__ gamma,
+                 int M, int K, int seg, int seg_pad, int ntiles, int KS, bf16_t* __restrict__ frag, int64_t frag_bs) {
+    const int b = blockIdx.y;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;          // (mt, ks, lane)
+    if (e >= (int64_t)ntiles * KS * 64) return;
+    const int lane = (int)(e & 63), ks = (int)((e >> 6) % KS), mt = (int)((e >> 6) / KS);
+    const int rr = lane & 15;
+    const int pos = 32 * (mt >> 1) + 8 * (rr >> 2) + 4 * (mt & 1) + (rr & 3);
+    const int ch = src_channel(pos, seg, seg_pad, M);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = 32 * ks + 8 * (lane >> 4) + j;
+        float x = 0.f;
+        if (ch >= 0 && k < K) {
+            x = w[(int64_t)b * w_bs + (int64_t)ch * ldw + k];
+            if (gamma != nullptr) x *= gamma[k];
+        }
+        v[j] = x;
+    }
+    *reinterpret_cast<u32x4*>(frag + (int64_t)b * frag_bs + e * 8) = pack8(v);
+}
+
+// s[pos] = sum_k bf16(w[ch][k] gamma[k]) (the rounded values, so that the mean term cancels what the product adds);
+// c[pos] = sum_k w[ch][k] beta[k] + bias[ch];  zero at padding positions.  One thread per position.
+__global__ void __launch_bounds__(256)
+pk_prep_sc_kernel(const float* __restrict__ w, int ldw, const float* __restrict__ gamma, const float* __restrict__ beta,
+                  const float* __restrict__ bias, int M, int K, int seg, int seg_pad, int npos,
+                  float* __restrict__ s, float* __restrict__ c) {
+    const int pos = blockIdx.x * 256 + threadIdx.x;
+    if (pos >= npos) return;
+    const int ch = src_channel(pos, seg, seg_pad, M);
+    float ss = 0.f, cc = 0.f;
+    if (ch >= 0) {
+        for (int k = 0; k < K; ++k) {
+            const float x = w[(int64_t)ch * ldw + k];
+            if (gamma != nullptr) ss += bf_lo(to_bf16_bits(x * gamma[k]));
+            if (beta != nullptr) cc = fmaf(x, beta[k], cc);
+        }
+        if (bias != nullptr) cc += bias[ch];
+    }
+    s[pos] = ss;
+    c[pos] = cc;
+}
+
+// depthwise weights per channel block: 72 taps [tap][8 channels] + 8 biases
+__global__ void __launch_bounds__(256)
+pk_prep_dw_kernel(const float* __restrict__ w, const float* __restrict__ bias, int C, int seg, int seg_pad, int Cb,
+                  float* __restrict__ out) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= Cb * 80) return;
+    const int cb = e / 80, r = e % 80, tap = r / 8, j = r % 8;
+    const int ch = src_channel(cb * 8 + j, seg, seg_pad, C);
+    float v = 0.f;
+    if (ch >= 0) v = tap < 9 ? w[ch * 9 + tap] : (bias != nullptr ? bias[ch] : 0.f);
+    out[e] = v;
+}
+
+int pk_prep_a_launch(const float* w, int64_t w_bs, int ldw, const float* gamma, int M, int K, int seg, int seg_pad,
+                     int ntiles, int KS, bf16_t* frag, int64_t frag_bs, int nb, hipStream_t stream) {
+    const int64_t n = (int64_t)ntiles * KS * 64;
+    hipLaunchKernelGGL(pk_prep_a_kernel, dim3((unsigned)cdiv(n, 256), nb), dim3(256), 0, stream, w, w_bs, ldw, gamma, M, K,
+                       seg, seg_pad, ntiles, KS, frag, frag_bs);
+    RST_LAUNCH_CHECK();
+    return RST_OK;
+}
+int pk_prep_sc_launch(const float* w, int ldw, const float* gamma, const float* beta, const float* bias, int M, int K,
+                      int seg, int seg_pad, int npos, float* s, float* c, hipStream_t stream) {
+    hipLaunchKernelGGL(pk_prep_sc_kernel, dim3((unsigned)cdiv(npos, 256)), dim3(256), 0, stream, w, ldw, gamma, beta, bias,
+                       M, K, seg, seg_pad, npos, s, c);
+    RST_LAUNCH_CHECK();
+    return RST_OK;
+}
+int pk_prep_dw_launch(const float* w, const float* bias, int C, int seg, int seg_pad, int Cb, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(pk_prep_dw_kernel, dim3((unsigned)cdiv(Cb * 80, 256)), dim3(256), 0, stream, w, bias, C, seg, seg_pad, Cb, out);
+    RST_LAUNCH_CHECK();
+    return RST_OK;
+}
+
+// ---- 1x1 convolution ------------------------------------------------------------------------------------
+// A wave owns PAIRS pairs of 16-row tiles (its weight fragments stay in registers) and walks over a range of
+// pixels, 32 at a time.  Waves of a block take neighbouring row groups of the same pixels, so that the operand
+// chunks of the pixels are fetched from memory once per block.
+template <int KS, int PAIRS, bool LN>
+__global__ void __launch_bounds__(256)
+gemm_pk_kernel(const GemmPk g) {
+    // long K: the pixel operand of a whole tile no longer fits twice beside the weights -> 16-pixel tiles, one buffer
+    constexpr int NT = KS >= 8 ? 1 : 2;
+    constexpr int TILE = 16 * NT;
+    constexpr bool DOUBLE = KS < 8;
+    __shared__ __attribute__((aligned(16))) float sc[4][2][PAIRS * 32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_ = lane & 15, gq = lane >> 4;
+    int64_t id = (int64_t)blockIdx.x * 4 + wave;
+    const int group = (int)(id % g.ngroups); id /= g.ngroups;
+    const int chunk = (int)(id % g.nchunks);
+    const int b = (int)(id / g.nchunks);
+    const bool live = b < g.B;
+    const bool has_c = g.ln_c != nullptr;
+    if (has_c && live) {
+        for (int i = lane; i < PAIRS * 32; i += 64) {
+            sc[wave][0][i] = g.ln_s != nullptr ? g.ln_s[group * PAIRS * 32 + i] : 0.f;
+            sc[wave][1][i] = g.ln_c[group * PAIRS * 32 + i];
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+
+    bf16x8 a[PAIRS][2][KS];
+    {
+        const bf16x8* Ap = reinterpret_cast<const bf16x8*>(g.A) + (int64_t)b * g.a_bs + (int64_t)group * PAIRS * 2 * KS * 64 + lane;
+#pragma unroll
+        for (int p = 0; p < PAIRS; ++p)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) a[p][h][ks] = Ap[((p * 2 + h) * KS + ks) * 64];
+    }
+    const int64_t N = g.N;
+    const bf16x8* Xp = reinterpret_cast<const bf16x8*>(g.X + (int64_t)b * g.x_bs);
+    u32x4* Yp = reinterpret_cast<u32x4*>(g.Y + (int64_t)b * g.y_bs);
+    const u32x4* Rp = g.R != nullptr ? reinterpret_cast<const u32x4*>(g.R + (int64_t)b * g.r_bs) : nullptr;
+    const int64_t p0 = (int64_t)chunk * g.chunk_px;
+    const int64_t p1 = p0 + g.chunk_px < N ? p0 + g.chunk_px : N;
+    const float invK = 1.0f / (float)g.K;
+
+    auto load = [&](bf16x8 (&dst)[KS][NT], int64_t n0) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int cb = 4 * ks + gq;
+                const int64_t px = n0 + nt * 16 + n_;
+                bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (cb < g.Kb && px < p1) v = Xp[(int64_t)cb * N + px];
+                dst[ks][nt] = v;
+            }
+    };
+    auto body = [&](const bf16x8 (&x)[KS][NT], int64_t n0) {
+        f32x4 acc[PAIRS][2][NT];
+#pragma unroll
+        for (int p = 0; p < PAIRS; ++p)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[p][h][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int p = 0; p < PAIRS; ++p)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[p][h][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[p][h][ks], x[ks][nt], acc[p][h][nt], 0, 0, 0);
+        float mean[NT], rstd[NT];
+        if (LN) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    float v[8];
+                    unpack8(__builtin_bit_cast(u32x4, x[ks][nt]), v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { s1 += v[j]; s2 = fmaf(v[j], v[j], s2); }
+                }
+                s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+                s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+                const float m = s1 * invK;
+                const float var = fmaxf(s2 * invK - m * m, 0.f);
+                mean[nt] = g.ln_mode == 1 ? m : 0.f;
+                rstd[nt] = 1.0f / sqrtf(var + 1e-5f);
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < PAIRS; ++p) {
+            const int cb = (group * PAIRS + p) * 4 + gq;
+            float s8[8], c8[8];
+            if (has_c) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s8[j] = sc[wave][0][p * 32 + gq * 8 + j]; c8[j] = sc[wave][1][p * 32 + gq * 8 + j]; }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int64_t px = n0 + nt * 16 + n_;
+                if (cb >= g.Mb || px >= p1) continue;
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[r] = acc[p][0][nt][r]; v[4 + r] = acc[p][1][nt][r]; }
+                if (LN) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = fmaf(fmaf(-mean[nt], s8[j], v[j]), rstd[nt], c8[j]);
+                } else if (has_c) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += c8[j];
+                }
+                if (Rp != nullptr) {
+                    float r8[8];
+                    unpack8(Rp[(int64_t)cb * N + px], r8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += r8[j];
+                }
+                Yp[(int64_t)cb * N + px] = pack8(v);
+            }
+        }
+    };
+
+    if constexpr (DOUBLE) {
+        bf16x8 t0[KS][NT], t1[KS][NT];
+        load(t0, p0);
+        for (int64_t n0 = p0; n0 < p1; n0 += 2 * TILE) {
+            load(t1, n0 + TILE);
+            body(t0, n0);
+            if (n0 + TILE < p1) {
+                load(t0, n0 + 2 * TILE);
+                body(t1, n0 + TILE);
+            }
+        }
+    } else {
+        bf16x8 t0[KS][NT];
+        for (int64_t n0 = p0; n0 < p1; n0 += TILE) {
+            load(t0, n0);
+            body(t0, n0);
+        }
+    }
+}
+
+template <int KS, int PAIRS>
+static int gemm_pk_go(const GemmPk& g, hipStream_t stream, int64_t blocks) {
+    if (g.ln_mode != 0)
+        hipLaunchKernelGGL((gemm_pk_kernel<KS, PAIRS, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g);
+    else
+        hipLaunchKernelGGL((gemm_pk_kernel<KS, PAIRS, false>), dim3((unsigned)blocks), dim3(256), 0, stream, g);
+    RST_LAUNCH_CHECK();
+    return RST_OK;
+}
+
+// pairs of 16-row tiles a wave keeps for a product with `Kb` input and `Mb` output channel blocks
+int gemm_pk_pairs(int Kb, int Mb) {
+    const int KS = (int)cdiv(Kb, 4), np = (int)cdiv(Mb, 4);
+    if (KS <= 2) {
+        if (np <= 2) return 2;
+        if (np % 5 == 0 || np > 8 || np == 5) return 5;
+        return 4;
+    }
+    if (KS <= 4) return 3;
+    if (KS <= 6) return 2;
+    return 1;
+}
+int gemm_pk_ks(int Kb) {
+    const int KS = (int)cdiv(Kb, 4);
+    const int have[] = {1, 2, 3, 4, 6, 8, 12, 15};
+    for (int k : have) if (KS <= k) return k;
+    return -1;
+}
+bool gemm_pk_supported(int K, int M) { return K > 0 && M > 0 && gemm_pk_ks((int)cdiv(K, 8)) > 0; }
+
+int gemm_pk_launch(GemmPk g, hipStream_t stream) {
+    const int KS = gemm_pk_ks(g.Kb);
+    RST_REQUIRE(KS > 0, "bf16 1x1 convolution: %d input channels not supported (at most 480)", g.Kb * 8);
+    RST_REQUIRE(aligned16(g.A) && aligned16(g.X) && aligned16(g.Y) && aligned16(g.R), "bf16 1x1 convolution: operands must be 16-byte aligned");
+    const int P = gemm_pk_pairs(g.Kb, g.Mb);
+    g.ngroups = (int)cdiv(cdiv(g.Mb, 4), P);
+    // enough wave-sized work items for every SIMD to hold two, each at least 4 tiles of 32 pixels long
+    int64_t chunk = round_up(cdiv(g.N * g.B * g.ngroups, 4096), 64);
+    if (chunk < 128) chunk = 128;
+    g.chunk_px = chunk;
+    g.nchunks = (int)cdiv(g.N, chunk);
+    const int64_t items = (int64_t)g.ngroups * g.nchunks * g.B;
+    const int64_t blocks = cdiv(items, 4);
+    RST_REQUIRE(blocks < (1ll << 31), "bf16 1x1 convolution: grid too large");
+    const double px = (double)g.N * g.B;
+    ProfScope prof(stream, g.ln_mode ? "pk_gemm_ln" : "pk_gemm", 2.0 * px * g.Mb * 8 * g.Kb * 8,
+                   px * 2.0 * (g.Kb * 8 + g.Mb * 8 * (g.R ? 2 : 1)));
+#define PK_CASE(ks, p) if (KS == ks && P == p) return gemm_pk_go<ks, p>(g, stream, blocks)
+    PK_CASE(1, 2); PK_CASE(1, 4); PK_CASE(1, 5);
+    PK_CASE(2, 2); PK_CASE(2, 4); PK_CASE(2, 5);
+    PK_CASE(3, 3); PK_CASE(4, 3); PK_CASE(6, 2);
+    PK_CASE(8, 1); PK_CASE(12, 1); PK_CASE(15, 1);
+#undef PK_CASE
+    return fail(RST_ERR_INVALID, "bf16 1x1 convolution: no kernel for KS=%d pairs=%d", KS, P);
+}
+
+// ---- depthwise 3x3 (+ GELU gate) ----------------------------------------------------------------------
+// gelu(x) = x * Phi(x), erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7), branch-free
+__device__ __forceinline__ float pk_gelu(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(z * z * -1.44269504088896340736f);
+    const float q = p * t * e;
+    const float phi = x >= 0.f ? fmaf(-0.5f, q, 1.0f) : 0.5f * q;
+    return x * phi;
+}
+
+// One thread = one pixel column of a strip of rows x 8 channels (x 2 halves when gated).  An input row adds
+// to the three output rows it touches; finished rows leave as one 16-byte chunk.
+// grid = (ceil(W * strips / 256), Cb_out, B)
+template <bool GATE>
+__global__ void __launch_bounds__(256)
+dw_pk_kernel(const DwPk a) {
+    const int cb = blockIdx.y, b = blockIdx.z;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int strip = t / a.W, x = t % a.W;
+    const int y0 = strip * a.rows;
+    if (y0 >= a.H) return;
+    const int y1 = y0 + a.rows < a.H ? y0 + a.rows : a.H;
+    constexpr int NH = GATE ? 2 : 1;
+    const int64_t N = (int64_t)a.H * a.W;
+    const u32x4* X[NH];
+    const float* Wt[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+        const int c = cb + h * a.gate_off;
+        X[h] = reinterpret_cast<const u32x4*>(a.x + (int64_t)b * a.x_bs) + (int64_t)c * N;
+        Wt[h] = a.wp + c * 80;
+    }
+    u32x4* Y = reinterpret_cast<u32x4*>(a.y + (int64_t)b * a.y_bs) + (int64_t)cb * N;
+    float acc[NH][3][8];
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[h][r][j] = 0.f;
+    const bool hasl = x > 0, hasr = x + 1 < a.W;
+    for (int i = y0 - 1; i <= y1; ++i) {
+        if (i >= 0 && i < a.H) {
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                const u32x4* row = X[h] + (int64_t)i * a.W + x;
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                const u32x4 wl = hasl ? row[-1] : z, wm = row[0], wr = hasr ? row[1] : z;
+                float l[8], m[8], r[8];
+                unpack8(wl, l); unpack8(wm, m); unpack8(wr, r);
+                // input row i is row dy of the window of output row i + 1 - dy; acc[h][dy] collects that output row
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        acc[h][dy][j] = fmaf(Wt[h][(dy * 3 + 0) * 8 + j], l[j],
+                                        fmaf(Wt[h][(dy * 3 + 1) * 8 + j], m[j],
+                                        fmaf(Wt[h][(dy * 3 + 2) * 8 + j], r[j], acc[h][dy][j])));
+            }
+        }
+        // output row i - 1 is complete (it has seen input rows i-2, i-1, i): it sits in acc[.][2]
+        const int yo = i - 1;
+        if (yo >= y0) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d0 = acc[0][2][j] + Wt[0][72 + j];
+                if (GATE) v[j] = pk_gelu(d0) * (acc[NH - 1][2][j] + Wt[NH - 1][72 + j]);
+                else v[j] = d0;
+            }
+            Y[(int64_t)yo * a.W + x] = pack8(v);
+        }
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { acc[h][2][j] = acc[h][1][j]; acc[h][1][j] = acc[h][0][j]; acc[h][0][j] = 0.f; }
+    }
+}
+
+int dw_pk_launch(DwPk a, hipStream_t stream) {
+    RST_REQUIRE(a.x && a.wp && a.y, "bf16 depthwise: null operand");
+    RST_REQUIRE(aligned16(a.x) && aligned16(a.y), "bf16 depthwise: operands must be 16-byte aligned");
+    a.rows = a.H >= 64 ? 16 : 8;
+    if (a.rows > a.H) a.rows = a.H;
+    const int strips = (int)cdiv(a.H, a.rows);
+    const dim3 grid((unsigned)cdiv((int64_t)a.W * strips, 256), a.Cb_out, a.B);
+    const double el = (double)a.B * a.Cb_out * 8 * a.H * a.W;
+    if (a.gate_off > 0) {
+        ProfScope prof(stream, "pk_dw_gate", el * 50.0, el * 2.0 * 3.0);
+        hipLaunchKernelGGL(dw_pk_kernel<true>, grid, dim3(256), 0, stream, a);
+    } else {
+        ProfScope prof(stream, "pk_dw", el * 18.0, el * 2.0 * 2.0);
+        hipLaunchKernelGGL(dw_pk_kernel<false>, grid, dim3(256), 0, stream, a);
+    }
+    RST_LAUNCH_CHECK();
+    return RST_OK;
+}
+
+// ---- Gram matrices q k^T and squared norms over the pixels --------------------------------------------
+// A wave takes a T x T block of 16 x 16 tiles of one (sample, head) over one range of pixels, 32 at a time:
+// the 16-byte chunks of q and k go to a wave-private LDS image as they are, and come back transposed
+// (8 pixels of one channel per lane) through ds_read_b64_tr_b16.  The squared norms are the diagonals of
+// q q^T and k k^T, taken by the matrix pipe as well.  Every wave writes its own slab.
+template <int T>
+__global__ void __launch_bounds__(256)
+gram_pk_kernel(const GramPk g) {
+    constexpr int CBS = 576;                           // bytes between channel blocks of the image (512 + 64: bank spread)
+    constexpr int IMG = 2 * T * CBS;                   // one operand
+    __shared__ __attribute__((aligned(16))) char lds[4][2 * IMG];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t id = (int64_t)blockIdx.x * 4 + wave;
+    const int nsub = g.nsub;
+    const int sub = (int)(id % (nsub * nsub)); id /= nsub * nsub;
+    const int split = (int)(id % g.splits);
+    const int bh = (int)(id / g.splits);
+    if (bh >= g.B * g.heads) return;                   // no barrier in this kernel
+    const int sm = sub / nsub, sn = sub % nsub;
+    const int b = bh / g.heads, h = bh % g.heads;
+    const int64_t N = g.N;
+    const u32x4* Q = reinterpret_cast<const u32x4*>(g.Q + (int64_t)b * g.bs) + (int64_t)(h * g.cb + sm * 2 * T) * N;
+    const u32x4* Kp = reinterpret_cast<const u32x4*>(g.Kx + (int64_t)b * g.bs) + (int64_t)(h * g.cb + sn * 2 * T) * N;
+    const int64_t p0 = (int64_t)split * g.chunk_px;
+    const int64_t p1 = p0 + g.chunk_px < N ? p0 + g.chunk_px : N;
+    char* img = lds[wave];
+    const uint32_t img_addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)img;   // LDS byte address
+
+    f32x4 acc[T][T], accq[T], acck[T];
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+        accq[i] = acck[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < T; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // transposed-read address of this lane inside one operand image, for tile 0, first block of 4 pixels
+    const int l16 = lane & 15, gq = lane >> 4;
+    const int tq = l16 >> 2, tp = l16 & 3;
+    const uint32_t tr_off = (uint32_t)((tp >> 1) * CBS + (8 * gq + tq) * 16 + (tp & 1) * 8);
+
+    u32x4 rq[T], rk[T];
+    auto gload = [&](int64_t n0) {
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            const int idx = i * 64 + lane, cbl = idx >> 5;
+            const int64_t px = n0 + (idx & 31);
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            rq[i] = px < p1 ? Q[(int64_t)cbl * N + px] : z;
+            rk[i] = px < p1 ? Kp[(int64_t)cbl * N + px] : z;
+        }
+    };
+    gload(p0);
+    for (int64_t n0 = p0; n0 < p1; n0 += 32) {
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            const int idx = i * 64 + lane;
+            const int off = (idx >> 5) * CBS + (idx & 31) * 16;
+            *reinterpret_cast<u32x4*>(img + off) = rq[i];
+            *reinterpret_cast<u32x4*>(img + IMG + off) = rk[i];
+        }
+        gload(n0 + 32);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        bf16x8 fq[T], fk[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            s16x4 q0, q1, k0, k1;
+            const uint32_t aq = img_addr + tr_off + t * 2 * CBS, ak = aq + IMG;
+            asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:64\n\t"
+                         "ds_read_b64_tr_b16 %2, %5\n\tds_read_b64_tr_b16 %3, %5 offset:64\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(q0), "=&v"(q1), "=&v"(k0), "=&v"(k1) : "v"(aq), "v"(ak) : "memory");
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            const s16x8 qq = {q0[0], q0[1], q0[2], q0[3], q1[0], q1[1], q1[2], q1[3]};
+            const s16x8 kk = {k0[0], k0[1], k0[2], k0[3], k1[0], k1[1], k1[2], k1[3]};
+            fq[t] = __builtin_bit_cast(bf16x8, qq);
+            fk[t] = __builtin_bit_cast(bf16x8, kk);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+#pragma unroll
+            for (int j = 0; j < T; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[i], fk[j], acc[i][j], 0, 0, 0);
+            if (sn == 0) accq[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[i], fq[i], accq[i], 0, 0, 0);
+            if (sm == 0) acck[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[i], fk[i], acck[i], 0, 0, 0);
+        }
+    }
+    const int c = g.cb * 8;
+    float* out = g.partial + ((int64_t)bh * g.splits + split) * c * c;
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int j = 0; j < T; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                out[(int64_t)((sm * T + i) * 16 + 4 * gq + r) * c + (sn * T + j) * 16 + l16] = acc[i][j][r];
+    float* oq = g.sqq + ((int64_t)bh * g.splits + split) * c;
+    float* ok = g.sqk + ((int64_t)bh * g.splits + split) * c;
+#pragma unroll
+    for (int i = 0; i < T; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (l16 == 4 * gq + r) {
+                if (sn == 0) oq[(sm * T + i) * 16 + l16] = accq[i][r];
+                if (sm == 0) ok[(sn * T + i) * 16 + l16] = acck[i][r];
+            }
+}
+
+static int gram_pk_tiles(int c) {
+    const int t = c / 16;
+    if (c % 16 != 0 || t < 1) return 0;
+    for (int T = 3; T >= 1; --T) if (t % T == 0) return T;
+    return 0;
+}
+bool gram_pk_supported(int c) { return gram_pk_tiles(c) > 0 && c <= 192; }
+
+void gram_pk_plan(int c, int64_t N, int BH, int* splits, int64_t* chunk) {
+    const int T = gram_pk_tiles(c), nsub = T > 0 ? c / 16 / T : 1;
+    // about four waves per SIMD over the chip, at least 8 tiles of 32 pixels each
+    int64_t want = cdiv(4096, (int64_t)BH * nsub * nsub);
+    if (want < 1) want = 1;
+    int64_t ch = round_up(cdiv(N, want), 32);
+    if (ch < 256) ch = 256;
+    *chunk = ch;
+    *splits = (int)cdiv(N, ch);
+}
+
+int gram_pk_launch(GramPk g, hipStream_t stream) {
+    const int c = g.cb * 8;
+    const int T = gram_pk_tiles(c);
+    RST_REQUIRE(T > 0 && c <= 192, "bf16 attention: %d channels per head not supported (multiples of 16 up to 192)", c);
+    RST_REQUIRE(aligned16(g.Q) && aligned16(g.Kx), "bf16 attention: operands must be 16-byte aligned");
+    g.nsub = c / 16 / T;
+    const int64_t items = (int64_t)g.nsub * g.nsub * g.splits * g.B * g.heads;
+    const double px = (double)g.N * g.B * g.heads;
+    ProfScope prof(stream, "pk_gram", 2.0 * px * c * (c + 2), px * 2.0 * 2.0 * c);
+    const dim3 grid((unsigned)cdiv(items, 4));
+    if (T == 3) hipLaunchKernelGGL(gram_pk_kernel<3>, grid, dim3(256), 0, stream, g);
+    else if (T == 2) hipLaunchKernelGGL(gram_pk_kernel<2>, grid, dim3(256), 0, stream, g);
+    else hipLaunchKernelGGL(gram_pk_kernel<1>, grid, dim3(256), 0, stream, g);
+    RST_LAUNCH_CHECK();
+    return RST_OK;
+}
+
+// ---- layout conversion: planar NCHW (fp32 or bf16) <-> channel-packed bf16 ----------------------------
+// one thread = 2 neighbouring pixels x one channel block.  Channels beyond C read as zero / are not written.
+template <typename SRC>
+__global__ void __launch_bounds__(256)
+pk_pack_kernel(const SRC* __restrict__ src, bf16_t* __restrict__ dst, int C, int Cb, int64_t N) {
+    const int64_t pp = (int64_t)blockIdx.x * 256 + threadIdx.x;        // pixel pair
+    const int cb = blockIdx.y, b = blockIdx.z;
+    if (pp * 2 >= N) return;
+    float v0[8], v1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ch = cb * 8 + j;
+        v0[j] = v1[j] = 0.f;
+        if (ch < C) {
+            const SRC* p = src + ((int64_t)b * C + ch) * N + pp * 2;
+            if constexpr (sizeof(SRC) == 4) { v0[j] = p[0]; v1[j] = p[1]; }
+            else { const uint32_t w = *reinterpret_cast<const uint32_t*>(p); v0[j] = bf_lo(w); v1[j] = bf_hi(w); }
+        }
+    }
+    u32x4* d = reinterpret_cast<u32x4*>(dst) + ((int64_t)b * Cb + cb) * N + pp * 2;
+    d[0] = pack8(v0);
+    d[1] = pack8(v1);
+}
+template <typename DST>
+__global__ void __launch_bounds__(256)
+pk_unpack_kernel(const bf16_t* __restrict__ src, DST* __restrict__ dst, int C, int Cb, int64_t N) {
+    const int64_t pp = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int cb = blockIdx.y, b = blockIdx.z;
+    if (pp * 2 >= N) return;
+    const u32x4* s = reinterpret_cast<const u32x4*>(src) + ((int64_t)b * Cb + cb) * N + pp * 2;
+    const u32x4 w0 = s[0], w1 = s[1];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ch = cb * 8 + j;
+        if (ch >= C) continue;
+        const uint32_t a = w0[j >> 1], c = w1[j >> 1];
+        DST* p = dst + ((int64_t)b * C + ch) * N + pp * 2;
+        if constexpr (sizeof(DST) == 4) {
+            p[0] = (j & 1) ? bf_hi(a) : bf_lo(a);
+            p[1] = (j & 1) ? bf_hi(c) : bf_lo(c);
+        } else {
+            const uint32_t lo = (j & 1) ? (a >> 16) : (a & 0xffffu), hi = (j & 1) ? (c & 0xffff0000u) : (c << 16);
+            *reinterpret_cast<uint32_t*>(p) = lo | hi;
+        }
+    }
+}
+
+int pk_pack_launch(const void* src, int src_is_fp32, bf16_t* dst, int B, int C, int64_t N, hipStream_t stream) {
+    RST_REQUIRE(src && dst && B > 0 && C > 0 && N > 0 && N % 2 == 0, "bf16 pack: bad shape B=%d C=%d N=%lld (N must be even)", B, C, (long long)N);
+    RST_REQUIRE(aligned16(dst) && (reinterpret_cast<uintptr_t>(src) & 3u) == 0, "bf16 pack: misaligned operand");
+    const int Cb = (int)cdiv(C, 8);
+    const dim3 grid((unsigned)cdiv(N / 2, 256), Cb, B);
+    ProfScope prof(stream, "pk_pack", 0.0, (double)B * C * N * (src_is_fp32 ? 6.0 : 4.0));
+    if (src_is_fp32) hipLaunchKernelGGL(pk_pack_kernel<float>, grid, dim3(256), 0, stream, static_cast<const float*>(src), dst, C, Cb, N);
+    else hipLaunchKernelGGL(pk_pack_kernel<bf16_t>, grid, dim3(256), 0, stream, static_cast<const bf16_t*>(src), dst, C, Cb, N);
+    RST_LAUNCH_CHECK();
+    return RST_OK;
+}
+int pk_unpack_launch(const bf16_t* src, void* dst, int dst_is_fp32, int B, int C, int64_t N, hipStream_t stream) {
+    RST_REQUIRE(src && dst && B > 0 && C > 0 && N > 0 && N % 2 == 0, "bf16 unpack: bad shape B=%d C=%d N=%lld (N must be even)", B, C, (long long)N);
+    RST_REQUIRE(aligned16(src) && (reinterpret_cast<uintptr_t>(dst) & 3u) == 0, "bf16 unpack: misaligned operand");
+    const int Cb = (int)cdiv(C, 8);
+    const dim3 grid((unsigned)cdiv(N / 2, 256), Cb, B);
+    ProfScope prof(stream, "pk_unpack", 0.0, (double)B * C * N * (dst_is_fp32 ? 6.0 : 4.0));
+    if (dst_is_fp32) hipLaunchKernelGGL(pk_unpack_kernel<float>, grid, dim3(256), 0, stream, src, static_cast<float*>(dst), C, Cb, N);
+    else hipLaunchKernelGGL(pk_unpack_kernel<bf16_t>, grid, dim3(256), 0, stream, src, static_cast<bf16_t*>(dst), C, Cb, N);
+    RST_LAUNCH_CHECK();
+    return RST_OK;
+}
+
+}  // namespace rst

@@ -135,4 +135,53 @@ size_t rowsum_ws_bytes(int B, int rows, int64_t N);
 int rowsum_launch(const float* x, int64_t x_bstride, float* out, int B, int rows, int64_t N,
                   void* ws, size_t ws_bytes, hipStream_t stream);
 
+// ---- bf16_pk.hip: bf16 storage path (inference).  Activations are channel-packed bf16, [B][Cb][N][8] with
+// Cb = ceil(C/8): one 16-byte chunk holds 8 consecutive channels of one pixel; sums are fp32 ----
+typedef uint16_t bf16_t;                 // raw bits of a bfloat16
+// 1x1 convolution Y[b] = A[b] X[b] (+c) (+R[b]) or, with ln_mode != 0 (as GemmNN::ln_mode), the channel LayerNorm of
+// X folded in.  A comes as MFMA operand fragments written by pk_prep_a_launch for gemm_pk_pairs(Kb, Mb) pairs per wave.
+struct GemmPk {
+    const bf16_t* A; int64_t a_bs;       // a_bs: 16-byte units between the samples' fragments (0: shared weights)
+    const bf16_t* X; int64_t x_bs;       // strides in elements
+    bf16_t* Y;       int64_t y_bs;
+    const bf16_t* R; int64_t r_bs;       // residual in the layout of Y, or null (may alias Y)
+    const float* ln_s; const float* ln_c; // per output position (padded to whole wave groups); ln_c alone: bias
+    int ln_mode;
+    int K;                               // real input channels (divisor of the LayerNorm statistics)
+    int Kb, Mb;                          // channel blocks in / out
+    int B; int64_t N;
+    int ngroups, nchunks; int64_t chunk_px;   // filled by the launcher
+};
+int gemm_pk_pairs(int Kb, int Mb);
+int gemm_pk_ks(int Kb);                  // k-steps of 32 channels the kernel for Kb runs (padded), -1: unsupported
+int gemm_pk_launch(GemmPk g, hipStream_t stream);
+// source channels come as segments of `seg` channels, each padded to `seg_pad` positions in the packed buffer
+int pk_prep_a_launch(const float* w, int64_t w_bs, int ldw, const float* gamma, int M, int K, int seg, int seg_pad,
+                     int ntiles, int KS, bf16_t* frag, int64_t frag_bs, int nb, hipStream_t stream);
+int pk_prep_sc_launch(const float* w, int ldw, const float* gamma, const float* beta, const float* bias, int M, int K,
+                      int seg, int seg_pad, int npos, float* s, float* c, hipStream_t stream);
+int pk_prep_dw_launch(const float* w, const float* bias, int C, int seg, int seg_pad, int Cb, float* out, hipStream_t stream);
+// depthwise 3x3; gate_off > 0: y[cb] = gelu(d[cb]) * d[cb + gate_off]
+struct DwPk {
+    const bf16_t* x; int64_t x_bs; const float* wp;   // wp: [Cb][80] from pk_prep_dw_launch
+    bf16_t* y; int64_t y_bs;
+    int B, Cb_out, H, W; int gate_off;
+    int rows;                            // filled by the launcher
+};
+int dw_pk_launch(DwPk a, hipStream_t stream);
+// Gram matrices q k^T and squared row norms over the pixels: `splits` slabs per (sample, head)
+struct GramPk {
+    const bf16_t* Q; const bf16_t* Kx; int64_t bs;    // first channel block of q / k; elements between samples
+    int cb;                              // channel blocks per head
+    int heads, B; int64_t N;
+    int splits; int64_t chunk_px;        // from gram_pk_plan
+    float* partial; float* sqq; float* sqk;           // [BH][splits][c][c], [BH][splits][c] x 2
+    int nsub;                            // filled by the launcher
+};
+bool gram_pk_supported(int c);
+void gram_pk_plan(int c, int64_t N, int BH, int* splits, int64_t* chunk);
+int gram_pk_launch(GramPk g, hipStream_t stream);
+int pk_pack_launch(const void* src, int src_is_fp32, bf16_t* dst, int B, int C, int64_t N, hipStream_t stream);
+int pk_unpack_launch(const bf16_t* src, void* dst, int dst_is_fp32, int B, int C, int64_t N, hipStream_t stream);
+
 }  // namespace rst

@@ -1,0 +1,107 @@
+"""GPU parity of the bf16 storage path (rst_bf16_*) through the C ABI.
+
+Layout conversion is bit-exact against torch's round-to-nearest-even cast.  Arithmetic results are
+compared with the fp64 golden fixtures written from the reference module (tests/golden/block_*.npz) and
+with the fp64 oracle.  Tolerance: bf16 keeps 8 significant bits (half an ulp = 2^-9 ~ 2e-3 relative), a block
+rounds its activations six times between kernels, so a tensor may differ from the fp64 result by
+BF16_TOL = 2e-2 of its largest magnitude (max|a-b| / max|b|); measured values are a few 1e-3.  The
+end-to-end criterion of the bf16 path is PSNR: within 0.01 dB of the fp32 result."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import load
+from oracle import recipe
+
+pytestmark = pytest.mark.gpu
+BF16_TOL = 2e-2
+
+BF16_BLOCK_CASES = [c for c in recipe.BLOCK_CASES if c[1] % 8 == 0 and (c[1] // c[2]) % 16 == 0]
+
+
+def _maxrel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("C", [3, 8, 12, 48, 60])
+@pytest.mark.parametrize("src", [torch.float32, torch.bfloat16])
+def test_pack_unpack_exact(C, src):
+    from superresolution_amd import bf16
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(2, C, 6, 10, generator=g).to(src).cuda()
+    p = bf16.pack(x)
+    assert p.shape == (2, C, 6, 10) and p.data.shape == (2, (C + 7) // 8, 6, 10, 8)
+    ref = x.to(torch.bfloat16)
+    # layout: data[b, cb, y, x, j] = channel 8 cb + j (zero beyond C)
+    lay = torch.zeros(2, (C + 7) // 8 * 8, 6, 10, dtype=torch.bfloat16, device="cuda")
+    lay[:, :C] = ref
+    lay = lay.view(2, -1, 8, 6, 10).permute(0, 1, 3, 4, 2)
+    assert torch.equal(p.data.view(torch.int16), lay.contiguous().view(torch.int16))
+    for dt in (torch.float32, torch.bfloat16):
+        back = bf16.unpack(p, dt)
+        assert back.dtype == dt and torch.equal(back.float(), ref.float())
+
+
+@pytest.mark.parametrize("shape", [(48, 144), (96, 48), (384, 192), (192, 96), (60, 48), (120, 96), (240, 192), (480, 384), (16, 24)])
+@pytest.mark.parametrize("bias", [False, True])
+def test_conv1x1_vs_fp64(shape, bias):
+    from superresolution_amd import bf16
+    cin, cout = shape
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn(2, cin, 10, 14, generator=g).cuda()
+    w = (torch.randn(cout, cin, 1, 1, generator=g) / math.sqrt(cin)).cuda()
+    b = torch.randn(cout, generator=g).cuda() if bias else None
+    r = torch.randn(2, cout, 10, 14, generator=g).cuda()
+    px, pr = bf16.pack(x), bf16.pack(r)
+    y = bf16.unpack(bf16.conv1x1(px, w, b, pr), torch.float32)
+    # same inputs as the kernel sees (bf16-rounded activations and weights), exact arithmetic
+    xr, wr, rr = bf16.unpack(px, torch.float32).double(), w.bfloat16().double(), bf16.unpack(pr, torch.float32).double()
+    ref = torch.nn.functional.conv2d(xr, wr, None if b is None else b.double()) + rr
+    assert _maxrel(y, ref) < 4e-3          # one rounding of the result
+
+
+@pytest.mark.parametrize("case", BF16_BLOCK_CASES, ids=[c[0] for c in BF16_BLOCK_CASES])
+def test_block_vs_golden(case):
+    from superresolution_amd import bf16
+    from superresolution_amd.model.Restromer import TransformerBlock
+    tag, dim, heads, ln_type, bias, b, h, w = case
+    gold = load("block_" + tag)
+    sd, x, r = recipe.block_case_tensors(case, torch.float32)
+    blk = TransformerBlock(dim, heads, recipe.FFN_FACTOR, bias, ln_type)
+    blk.load_state_dict(sd, strict=True)
+    blk = blk.cuda()
+    with torch.no_grad():
+        p = bf16.pack(x.cuda())
+        bf16.block_(p, heads, blk.ffn.hidden_features, blk._params())
+        out = bf16.unpack(p, torch.float32)
+    a = out.double().cpu().numpy().reshape(-1)
+    idx = recipe.subsample_index(a.size)
+    ref = gold["out/v"].astype(np.float64)
+    err = np.abs(a[idx] - ref).max() / np.abs(ref).max()
+    assert np.isfinite(a).all()
+    assert err < BF16_TOL, f"{tag}: max rel err {err:.3e}"
+
+
+@pytest.mark.parametrize("case", [BF16_BLOCK_CASES[0]], ids=lambda c: c[0])
+def test_block_vs_oracle_large_mean(case):
+    """The folded LayerNorm takes the variance in one pass; inputs with a channel mean several sigma from zero."""
+    from oracle import restormer_oracle as orc
+    from superresolution_amd import bf16
+    from superresolution_amd.model.Restromer import TransformerBlock
+    tag, dim, heads, ln_type, bias, b, h, w = case
+    sd, x, r = recipe.block_case_tensors(case, torch.float32)
+    x = x + 3.0
+    blk = TransformerBlock(dim, heads, recipe.FFN_FACTOR, bias, ln_type)
+    blk.load_state_dict(sd, strict=True)
+    blk = blk.cuda()
+    with torch.no_grad():
+        p = bf16.pack(x.cuda())
+        xq = bf16.unpack(p, torch.float32).double().cpu()        # the block's actual input
+        bf16.block_(p, heads, blk.ffn.hidden_features, blk._params())
+        out = bf16.unpack(p, torch.float32)
+    sd64 = {k: v.double() for k, v in sd.items()}
+    ref = orc.transformer_block(xq, sd64, "", heads)
+    assert _maxrel(out, ref) < BF16_TOL
