@@ -175,22 +175,29 @@ def main():
     ap.add_argument("--mode", choices=["infer", "train", "tiled", "frame", "frame_sharded"], default="infer")
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--size", type=int, default=None)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="bf16: activations stored in bf16 between kernels, fp32 sums (infer and frame modes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.dtype == "bf16" and args.mode not in ("infer", "frame"):
+        raise SystemExit("--dtype bf16 is available for --mode infer and --mode frame")
     rank, world, local = dist_setup(args.gpus)
     dev = torch.device("cuda", local)
     net = build_model(0).to(dev)
+    prec = "fp32" if args.dtype == "f32" else "bf16-storage"
 
     if args.mode == "infer":
         B, S = args.batch or 16, args.size or 256
         x = torch.rand(B, 3, S, S, device=dev, generator=torch.Generator(device=dev).manual_seed(100 + rank))
+        if args.dtype == "bf16":
+            x = x.bfloat16()
         net.eval()
 
         def step():
             with torch.no_grad():
                 return net(x)
-        workload = f"Restormer(3,3,dim=48) fp32 inference, {B}x3x{S}x{S} per GPU"
+        workload = f"Restormer(3,3,dim=48) {prec} inference, {B}x3x{S}x{S} per GPU"
         metric = "restormer_inference_megapixels_per_sec"
     elif args.mode in ("tiled", "frame", "frame_sharded"):
         from superresolution_amd.parallel import sharded_frame_inference, tiled_inference
@@ -202,6 +209,8 @@ def main():
             Hh, Ww = (args.size, args.size) if args.size else (2160, 3840)
             seed = 100 if args.mode == "frame_sharded" else 100 + rank
         x = torch.rand(1, 3, Hh, Ww, device=dev, generator=torch.Generator(device=dev).manual_seed(seed))
+        if args.dtype == "bf16":
+            x = x.bfloat16()
 
         def step():
             with torch.no_grad():
@@ -215,7 +224,7 @@ def main():
         workload = (f"Restormer(3,3,dim=48) fp32 tiled inference of one 1x3x{Hh}x{Ww} image, 256-px tiles + 32-px overlap, tiles sharded over the GPUs"
                     if args.mode == "tiled" else
                     f"Restormer(3,3,dim=48) fp32 exact inference of one 1x3x{Hh}x{Ww} frame, rows sharded over the GPUs, output gathered on rank 0"
-                    if args.mode == "frame_sharded" else f"Restormer(3,3,dim=48) fp32 untiled inference, one 1x3x{Hh}x{Ww} frame per GPU")
+                    if args.mode == "frame_sharded" else f"Restormer(3,3,dim=48) {prec} untiled inference, one 1x3x{Hh}x{Ww} frame per GPU")
         metric = "restormer_inference_megapixels_per_sec"
         B, S = 1, Hh
     else:
@@ -248,7 +257,7 @@ def main():
     out = {
         "metric": metric, "value": round(mp / elapsed, 3), "unit": "MP/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-        "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": scaling, "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": workload, "global_batch": world * B, "input_hw": [Hh, Ww] if args.mode in ("tiled", "frame", "frame_sharded") else [S, S], "parallelism": {"tiled": f"tiles{world}", "frame_sharded": f"rows{world}"}.get(args.mode, f"dp{world}"),
                    "weights": "default init, seed 0"},
     }
@@ -260,7 +269,7 @@ def main():
         out["roofline"] = roof
         out["kernels"] = breakdown
         out["hip_kernel_ms_per_step"] = round(ktotal, 3)
-        if world == 1 and not args.no_cpu_baseline and args.mode == "infer":
+        if world == 1 and not args.no_cpu_baseline and args.mode == "infer" and args.dtype == "f32":
             out["cpu_baseline"] = cpu_baseline(net)
         print(json.dumps(out), flush=True)
     barrier(world)

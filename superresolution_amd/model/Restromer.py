@@ -231,11 +231,63 @@ class Restormer(nn.Module):
             self.skip_conv = nn.Conv2d(dim, w2, kernel_size=1, bias=bias)
         self.output = nn.Conv2d(dim, out_channels, kernel_size=3, stride=1, padding=1, bias=bias)
 
+    def _forward_bf16(self, inp_img):
+        """Inference with bf16 activations (a bf16 input, or an fp32 input under bf16 autocast): every
+        TransformerBlock and 1x1 convolution runs on the library's channel-packed bf16 tensors with fp32 sums
+        and fp32 parameters; the dense 3x3 convolutions run in bf16 through torch, the last layer and the
+        bilinear residual in fp32.  The result has the input's dtype."""
+        from .. import bf16 as pk
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError("the bf16 path is inference only: call it under torch.no_grad()")
+        bf = torch.bfloat16
+
+        def conv3(x, conv):
+            return F.conv2d(x, conv.weight.to(bf), None if conv.bias is None else conv.bias.to(bf), padding=1)
+
+        def stage(p, blocks):
+            for blk in blocks:
+                pk.block_(p, blk.attn.num_heads, blk.ffn.hidden_features, blk._params())
+            return p
+
+        def down(p, mod):
+            return pk.pack(F.pixel_unshuffle(conv3(pk.unpack(p), mod.body[0]), 2))
+
+        def up(p, mod):
+            return pk.pack(F.pixel_shuffle(conv3(pk.unpack(p), mod.body[0]), 2))
+
+        e1_in = pk.pack(conv3(inp_img.to(bf), self.patch_embed.proj))
+        skip = None
+        if self.dual_pixel_task:
+            skip = pk.unpack(pk.conv1x1(e1_in, self.skip_conv.weight, self.skip_conv.bias))
+        e1 = stage(e1_in, self.encoder_level1)                       # in place: e1_in is consumed
+        e2 = stage(down(e1, self.down1_2), self.encoder_level2)
+        e3 = stage(down(e2, self.down2_3), self.encoder_level3)
+        lat = stage(down(e3, self.down3_4), self.latent)
+        d3 = pk.conv1x1(pk.cat(up(lat, self.up4_3), e3), self.reduce_chan_level3.weight, self.reduce_chan_level3.bias)
+        d3 = stage(d3, self.decoder_level3)
+        d2 = pk.conv1x1(pk.cat(up(d3, self.up3_2), e2), self.reduce_chan_level2.weight, self.reduce_chan_level2.bias)
+        d2 = stage(d2, self.decoder_level2)
+        d1 = stage(stage(pk.cat(up(d2, self.up2_1), e1), self.decoder_level1), self.refinement)
+        upx = F.pixel_shuffle(conv3(pk.unpack(d1), self.output_upscale.body[0]), 2)
+        if self.dual_pixel_task:
+            out = conv3(upx + skip, self.output).float()
+        else:
+            base = F.interpolate(inp_img.float(), scale_factor=2, mode="bilinear", align_corners=False)
+            if self.output.weight.shape[0] <= 4:
+                bias = None if self.output.bias is None else self.output.bias.float()
+                out = ops.conv3x3_fewout(upx.float(), self.output.weight.float(), bias, base)
+            else:
+                out = conv3(upx, self.output).float() + base
+        return out.to(inp_img.dtype)
+
     def forward(self, inp_img):
         if inp_img.dim() != 4:
             raise RuntimeError(f"Restormer expects a 4-D NCHW tensor, got shape {tuple(inp_img.shape)}")
         if inp_img.shape[-2] % 8 or inp_img.shape[-1] % 8:
             raise RuntimeError(f"Restormer needs H and W divisible by 8, got {tuple(inp_img.shape[-2:])}")
+        if inp_img.dtype == torch.bfloat16 or (inp_img.is_cuda and torch.is_autocast_enabled()
+                                               and torch.get_autocast_gpu_dtype() == torch.bfloat16):
+            return self._forward_bf16(inp_img)
         e1_in = self.patch_embed(inp_img)
         e1 = self.encoder_level1(e1_in)
         e2 = self.encoder_level2(self.down1_2(e1))

@@ -105,3 +105,39 @@ def test_block_vs_oracle_large_mean(case):
     sd64 = {k: v.double() for k, v in sd.items()}
     ref = orc.transformer_block(xq, sd64, "", heads)
     assert _maxrel(out, ref) < BF16_TOL
+
+
+def _psnr(a, b):
+    mse = float(((a.double() - b.double()) ** 2).mean())
+    return 10.0 * math.log10(1.0 / mse)
+
+
+def test_model_bf16_end_to_end_psnr():
+    """Whole network, dim 48: the bf16 path against the fp32 path of this library (itself pinned to the reference
+    at 1e-4) on an image-like input, PSNR against a synthetic target within 0.01 dB, and the outputs close."""
+    import bench
+    net = bench.build_model(0).cuda().eval()
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(2, 3, 64, 96, generator=g).cuda()
+    with torch.no_grad():
+        ref = net(x)
+        out = net(x.bfloat16())
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out_ac = net(x)
+    assert out.dtype == torch.bfloat16 and out_ac.dtype == torch.float32
+    assert torch.isfinite(out.float()).all()
+    # a target at a realistic distance from the output (~30 dB)
+    target = (ref + 0.03 * torch.randn(ref.shape, generator=g).cuda()).clamp(0, 1)
+    for o in (out.float(), out_ac):
+        assert abs(_psnr(o, target) - _psnr(ref, target)) < 0.01
+    assert _maxrel(out_ac, ref) < BF16_TOL
+
+
+def test_bf16_path_refuses_training_and_cpu():
+    import bench
+    from superresolution_amd import bf16
+    net = bench.build_model(0).cuda()
+    with pytest.raises(RuntimeError):
+        net(torch.rand(1, 3, 16, 16, device="cuda").bfloat16())      # grad mode on
+    with pytest.raises(RuntimeError):
+        bf16.pack(torch.rand(1, 8, 4, 4))                             # CPU tensor
