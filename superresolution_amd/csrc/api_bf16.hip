@@ -62,7 +62,7 @@ int check_pk_desc(const rst_block_desc* d) {
     RST_REQUIRE(d->hidden > 0, "bf16 block: hidden=%d", d->hidden);
     RST_REQUIRE(d->C % 8 == 0, "bf16 block: C=%d must be a multiple of 8", d->C);
     RST_REQUIRE(gram_pk_supported(d->C / d->heads), "bf16 block: %d channels per head not supported (multiples of 16 up to 192)", d->C / d->heads);
-    RST_REQUIRE(((int64_t)d->H * d->W) % 2 == 0, "bf16 block: H*W must be even");
+    RST_REQUIRE(d->W % 2 == 0, "bf16 block: W=%d must be even", d->W);
     RST_REQUIRE(gemm_pk_ks(d->C / 8) > 0 && gemm_pk_ks(pad8(d->hidden) / 8) > 0, "bf16 block: C=%d / hidden=%d too wide (at most 480 input channels per product)", d->C, d->hidden);
     return RST_OK;
 }

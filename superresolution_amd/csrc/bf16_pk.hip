@@ -128,52 +128,46 @@ int pk_prep_dw_launch(const float* w, const float* bias, int C, int seg, int seg
 }
 
 // ---- 1x1 convolution ------------------------------------------------------------------------------------
-// A wave owns PAIRS pairs of 16-row tiles (its weight fragments stay in registers) and walks over a range of
-// pixels, 32 at a time.  Waves of a block take neighbouring row groups of the same pixels, so that the operand
-// chunks of the pixels are fetched from memory once per block.
-template <int KS, int PAIRS, bool LN>
+// A block keeps the weight fragments of `pb` pairs of 16-row tiles in LDS (fragment order: a wave reads 1 KB
+// contiguous per ds_read_b128, conflict-free) and walks over a range of pixels; each wave takes every fourth
+// tile of 16*NT pixels.  The pixel operand of a tile is fetched once, straight from memory into MFMA operand
+// registers (the next tile's is in flight meanwhile), and multiplied with one pair of row tiles after the
+// other: 8 output channels x NT pixels per lane and pair, stored as 16-byte chunks.
+// grid = (pixel chunks, row splits, samples)
+template <int KS, int NT, bool LN>
 __global__ void __launch_bounds__(256)
 gemm_pk_kernel(const GemmPk g) {
-    // long K: the pixel operand of a whole tile no longer fits twice beside the weights -> 16-pixel tiles, one buffer
-    constexpr int NT = KS >= 8 ? 1 : 2;
     constexpr int TILE = 16 * NT;
-    constexpr bool DOUBLE = KS < 8;
-    __shared__ __attribute__((aligned(16))) float sc[4][2][PAIRS * 32];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int pb = g.pb;
+    bf16x8* As = reinterpret_cast<bf16x8*>(smem);                        // [pb*2][KS][64]
+    float* sc = reinterpret_cast<float*>(smem + (size_t)pb * 2 * KS * 1024);   // [2][pb*32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_ = lane & 15, gq = lane >> 4;
-    int64_t id = (int64_t)blockIdx.x * 4 + wave;
-    const int group = (int)(id % g.ngroups); id /= g.ngroups;
-    const int chunk = (int)(id % g.nchunks);
-    const int b = (int)(id / g.nchunks);
-    const bool live = b < g.B;
+    const int msplit = blockIdx.y, b = blockIdx.z;
     const bool has_c = g.ln_c != nullptr;
-    if (has_c && live) {
-        for (int i = lane; i < PAIRS * 32; i += 64) {
-            sc[wave][0][i] = g.ln_s != nullptr ? g.ln_s[group * PAIRS * 32 + i] : 0.f;
-            sc[wave][1][i] = g.ln_c[group * PAIRS * 32 + i];
-        }
+    {
+        const u32x4* src = reinterpret_cast<const u32x4*>(g.A) + (int64_t)b * g.a_bs + (int64_t)msplit * pb * 2 * KS * 64;
+        u32x4* dst = reinterpret_cast<u32x4*>(smem);
+        for (int i = tid; i < pb * 2 * KS * 64; i += 256) dst[i] = src[i];
+        if (has_c)
+            for (int i = tid; i < pb * 32; i += 256) {
+                sc[i] = g.ln_s != nullptr ? g.ln_s[msplit * pb * 32 + i] : 0.f;
+                sc[pb * 32 + i] = g.ln_c[msplit * pb * 32 + i];
+            }
     }
     __syncthreads();
-    if (!live) return;
 
-    bf16x8 a[PAIRS][2][KS];
-    {
-        const bf16x8* Ap = reinterpret_cast<const bf16x8*>(g.A) + (int64_t)b * g.a_bs + (int64_t)group * PAIRS * 2 * KS * 64 + lane;
-#pragma unroll
-        for (int p = 0; p < PAIRS; ++p)
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) a[p][h][ks] = Ap[((p * 2 + h) * KS + ks) * 64];
-    }
     const int64_t N = g.N;
     const bf16x8* Xp = reinterpret_cast<const bf16x8*>(g.X + (int64_t)b * g.x_bs);
     u32x4* Yp = reinterpret_cast<u32x4*>(g.Y + (int64_t)b * g.y_bs);
     const u32x4* Rp = g.R != nullptr ? reinterpret_cast<const u32x4*>(g.R + (int64_t)b * g.r_bs) : nullptr;
-    const int64_t p0 = (int64_t)chunk * g.chunk_px;
+    const int64_t p0 = (int64_t)blockIdx.x * g.chunk_px;
     const int64_t p1 = p0 + g.chunk_px < N ? p0 + g.chunk_px : N;
     const float invK = 1.0f / (float)g.K;
+    const int Kb = g.Kb, Mb = g.Mb;
 
+    // no branch around a load: out-of-range lanes read a valid address and drop the value
     auto load = [&](bf16x8 (&dst)[KS][NT], int64_t n0) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
@@ -181,28 +175,13 @@ gemm_pk_kernel(const GemmPk g) {
             for (int nt = 0; nt < NT; ++nt) {
                 const int cb = 4 * ks + gq;
                 const int64_t px = n0 + nt * 16 + n_;
-                bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (cb < g.Kb && px < p1) v = Xp[(int64_t)cb * N + px];
-                dst[ks][nt] = v;
+                const bool ok = cb < Kb && px < p1;
+                const bf16x8 v = Xp[(int64_t)(cb < Kb ? cb : 0) * N + (px < p1 ? px : p1 - 1)];
+                const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                dst[ks][nt] = ok ? v : z;
             }
     };
     auto body = [&](const bf16x8 (&x)[KS][NT], int64_t n0) {
-        f32x4 acc[PAIRS][2][NT];
-#pragma unroll
-        for (int p = 0; p < PAIRS; ++p)
-#pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[p][h][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-            for (int p = 0; p < PAIRS; ++p)
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[p][h][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[p][h][ks], x[ks][nt], acc[p][h][nt], 0, 0, 0);
         float mean[NT], rstd[NT];
         if (LN) {
 #pragma unroll
@@ -223,21 +202,46 @@ gemm_pk_kernel(const GemmPk g) {
                 rstd[nt] = 1.0f / sqrtf(var + 1e-5f);
             }
         }
+        for (int p = 0; p < pb; ++p) {
+            const int cb = (msplit * pb + p) * 4 + gq;
+            const bool cb_ok = cb < Mb;
+            u32x4 rres[NT];
+            if (Rp != nullptr) {
 #pragma unroll
-        for (int p = 0; p < PAIRS; ++p) {
-            const int cb = (group * PAIRS + p) * 4 + gq;
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int64_t px = n0 + nt * 16 + n_;
+                    rres[nt] = Rp[(int64_t)(cb_ok ? cb : 0) * N + (px < p1 ? px : p1 - 1)];
+                }
+            }
+            f32x4 acc[2][NT];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[h][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const bf16x8* Ap = As + (size_t)p * 2 * KS * 64 + lane;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 a0 = Ap[ks * 64], a1 = Ap[(KS + ks) * 64];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, x[ks][nt], acc[0][nt], 0, 0, 0);
+                    acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, x[ks][nt], acc[1][nt], 0, 0, 0);
+                }
+            }
             float s8[8], c8[8];
             if (has_c) {
+                const f32x4* sp = reinterpret_cast<const f32x4*>(sc + p * 32 + gq * 8);
+                const f32x4* cp = reinterpret_cast<const f32x4*>(sc + pb * 32 + p * 32 + gq * 8);
+                const f32x4 sa = sp[0], sb = sp[1], ca = cp[0], cc = cp[1];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { s8[j] = sc[wave][0][p * 32 + gq * 8 + j]; c8[j] = sc[wave][1][p * 32 + gq * 8 + j]; }
+                for (int j = 0; j < 4; ++j) { s8[j] = sa[j]; s8[4 + j] = sb[j]; c8[j] = ca[j]; c8[4 + j] = cc[j]; }
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int64_t px = n0 + nt * 16 + n_;
-                if (cb >= g.Mb || px >= p1) continue;
                 float v[8];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { v[r] = acc[p][0][nt][r]; v[4 + r] = acc[p][1][nt][r]; }
+                for (int r = 0; r < 4; ++r) { v[r] = acc[0][nt][r]; v[4 + r] = acc[1][nt][r]; }
                 if (LN) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = fmaf(fmaf(-mean[nt], s8[j], v[j]), rstd[nt], c8[j]);
@@ -247,89 +251,86 @@ gemm_pk_kernel(const GemmPk g) {
                 }
                 if (Rp != nullptr) {
                     float r8[8];
-                    unpack8(Rp[(int64_t)cb * N + px], r8);
+                    unpack8(rres[nt], r8);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] += r8[j];
                 }
-                Yp[(int64_t)cb * N + px] = pack8(v);
+                if (cb_ok && px < p1) Yp[(int64_t)cb * N + px] = pack8(v);
             }
         }
     };
 
-    if constexpr (DOUBLE) {
-        bf16x8 t0[KS][NT], t1[KS][NT];
-        load(t0, p0);
-        for (int64_t n0 = p0; n0 < p1; n0 += 2 * TILE) {
-            load(t1, n0 + TILE);
-            body(t0, n0);
-            if (n0 + TILE < p1) {
-                load(t0, n0 + 2 * TILE);
-                body(t1, n0 + TILE);
-            }
-        }
-    } else {
-        bf16x8 t0[KS][NT];
-        for (int64_t n0 = p0; n0 < p1; n0 += TILE) {
-            load(t0, n0);
-            body(t0, n0);
+    bf16x8 t0[KS][NT], t1[KS][NT];
+    const int64_t first = p0 + (int64_t)wave * TILE;
+    load(t0, first);
+    for (int64_t n0 = first; n0 < p1; n0 += 8 * TILE) {
+        load(t1, n0 + 4 * TILE);
+        body(t0, n0);
+        if (n0 + 4 * TILE < p1) {
+            load(t0, n0 + 8 * TILE);
+            body(t1, n0 + 4 * TILE);
         }
     }
 }
 
-template <int KS, int PAIRS>
-static int gemm_pk_go(const GemmPk& g, hipStream_t stream, int64_t blocks) {
-    if (g.ln_mode != 0)
-        hipLaunchKernelGGL((gemm_pk_kernel<KS, PAIRS, true>), dim3((unsigned)blocks), dim3(256), 0, stream, g);
-    else
-        hipLaunchKernelGGL((gemm_pk_kernel<KS, PAIRS, false>), dim3((unsigned)blocks), dim3(256), 0, stream, g);
-    RST_LAUNCH_CHECK();
-    return RST_OK;
-}
-
-// pairs of 16-row tiles a wave keeps for a product with `Kb` input and `Mb` output channel blocks
-int gemm_pk_pairs(int Kb, int Mb) {
-    const int KS = (int)cdiv(Kb, 4), np = (int)cdiv(Mb, 4);
-    if (KS <= 2) {
-        if (np <= 2) return 2;
-        if (np % 5 == 0 || np > 8 || np == 5) return 5;
-        return 4;
-    }
-    if (KS <= 4) return 3;
-    if (KS <= 6) return 2;
-    return 1;
-}
 int gemm_pk_ks(int Kb) {
     const int KS = (int)cdiv(Kb, 4);
     const int have[] = {1, 2, 3, 4, 6, 8, 12, 15};
     for (int k : have) if (KS <= k) return k;
     return -1;
 }
+// pairs of 16-row tiles whose fragments a block holds in LDS (at most 56 KB), balanced over the row splits
+int gemm_pk_pairs(int Kb, int Mb) {
+    const int KS = gemm_pk_ks(Kb), np = (int)cdiv(Mb, 4);
+    if (KS <= 0) return 1;
+    int cap = 56 / (2 * KS);
+    if (cap < 1) cap = 1;
+    const int splits = (int)cdiv(np, cap);
+    return (int)cdiv(np, splits);
+}
 bool gemm_pk_supported(int K, int M) { return K > 0 && M > 0 && gemm_pk_ks((int)cdiv(K, 8)) > 0; }
+
+template <int KS, int NT>
+static int gemm_pk_go(const GemmPk& g, hipStream_t stream, dim3 grid, size_t lds) {
+    if (g.ln_mode != 0)
+        hipLaunchKernelGGL((gemm_pk_kernel<KS, NT, true>), grid, dim3(256), lds, stream, g);
+    else
+        hipLaunchKernelGGL((gemm_pk_kernel<KS, NT, false>), grid, dim3(256), lds, stream, g);
+    RST_LAUNCH_CHECK();
+    return RST_OK;
+}
 
 int gemm_pk_launch(GemmPk g, hipStream_t stream) {
     const int KS = gemm_pk_ks(g.Kb);
     RST_REQUIRE(KS > 0, "bf16 1x1 convolution: %d input channels not supported (at most 480)", g.Kb * 8);
     RST_REQUIRE(aligned16(g.A) && aligned16(g.X) && aligned16(g.Y) && aligned16(g.R), "bf16 1x1 convolution: operands must be 16-byte aligned");
-    const int P = gemm_pk_pairs(g.Kb, g.Mb);
-    g.ngroups = (int)cdiv(cdiv(g.Mb, 4), P);
-    // enough wave-sized work items for every SIMD to hold two, each at least 4 tiles of 32 pixels long
-    int64_t chunk = round_up(cdiv(g.N * g.B * g.ngroups, 4096), 64);
-    if (chunk < 128) chunk = 128;
+    RST_REQUIRE(g.B <= 65535, "bf16 1x1 convolution: batch %d exceeds 65535", g.B);
+    g.pb = gemm_pk_pairs(g.Kb, g.Mb);
+    g.ngroups = (int)cdiv(cdiv(g.Mb, 4), g.pb);
+    const int NT = KS <= 3 ? 4 : (KS <= 6 ? 2 : 1);
+    const int tile4 = 4 * 16 * NT;                       // pixels the four waves of a block take per round
+    // about two blocks per CU over the chip, each at least two rounds long
+    int64_t chunk = round_up(cdiv(g.N * g.B * g.ngroups, 512), tile4);
+    if (chunk < 2 * tile4) chunk = 2 * tile4;
     g.chunk_px = chunk;
     g.nchunks = (int)cdiv(g.N, chunk);
-    const int64_t items = (int64_t)g.ngroups * g.nchunks * g.B;
-    const int64_t blocks = cdiv(items, 4);
-    RST_REQUIRE(blocks < (1ll << 31), "bf16 1x1 convolution: grid too large");
+    const dim3 grid((unsigned)g.nchunks, (unsigned)g.ngroups, (unsigned)g.B);
+    const size_t lds = (size_t)g.pb * 2 * KS * 1024 + (size_t)g.pb * 32 * 2 * sizeof(float);
+    RST_REQUIRE(lds <= 64 * 1024, "bf16 1x1 convolution: LDS plan of %zu bytes", lds);
     const double px = (double)g.N * g.B;
     ProfScope prof(stream, g.ln_mode ? "pk_gemm_ln" : "pk_gemm", 2.0 * px * g.Mb * 8 * g.Kb * 8,
                    px * 2.0 * (g.Kb * 8 + g.Mb * 8 * (g.R ? 2 : 1)));
-#define PK_CASE(ks, p) if (KS == ks && P == p) return gemm_pk_go<ks, p>(g, stream, blocks)
-    PK_CASE(1, 2); PK_CASE(1, 4); PK_CASE(1, 5);
-    PK_CASE(2, 2); PK_CASE(2, 4); PK_CASE(2, 5);
-    PK_CASE(3, 3); PK_CASE(4, 3); PK_CASE(6, 2);
-    PK_CASE(8, 1); PK_CASE(12, 1); PK_CASE(15, 1);
-#undef PK_CASE
-    return fail(RST_ERR_INVALID, "bf16 1x1 convolution: no kernel for KS=%d pairs=%d", KS, P);
+    switch (KS) {
+        case 1: return gemm_pk_go<1, 4>(g, stream, grid, lds);
+        case 2: return gemm_pk_go<2, 4>(g, stream, grid, lds);
+        case 3: return gemm_pk_go<3, 4>(g, stream, grid, lds);
+        case 4: return gemm_pk_go<4, 2>(g, stream, grid, lds);
+        case 6: return gemm_pk_go<6, 2>(g, stream, grid, lds);
+        case 8: return gemm_pk_go<8, 1>(g, stream, grid, lds);
+        case 12: return gemm_pk_go<12, 1>(g, stream, grid, lds);
+        case 15: return gemm_pk_go<15, 1>(g, stream, grid, lds);
+    }
+    return fail(RST_ERR_INVALID, "bf16 1x1 convolution: no kernel for KS=%d", KS);
 }
 
 // ---- depthwise 3x3 (+ GELU gate) ----------------------------------------------------------------------
@@ -347,89 +348,128 @@ __device__ __forceinline__ float pk_gelu(float x) {
     return x * phi;
 }
 
-// One thread = one pixel column of a strip of rows x 8 channels (x 2 halves when gated).  An input row adds
-// to the three output rows it touches; finished rows leave as one 16-byte chunk.
-// grid = (ceil(W * strips / 256), Cb_out, B)
+// One thread = two neighbouring pixel columns of a strip of rows x 8 channels (x 2 halves when gated).  An input
+// row (four 16-byte chunks: x-1 .. x+2, the next row's already in flight) adds to the three output rows it
+// touches; finished rows leave as two 16-byte chunks.  The 72 taps + 8 biases of the channel block are the
+// same for the whole block and live in scalar registers.  No branch around a load: out-of-image chunks read a valid address and are zeroed.
+// grid = (ceil(W/2 * strips / 256), Cb_out, B)
 template <bool GATE>
 __global__ void __launch_bounds__(256)
-dw_pk_kernel(const DwPk a) {
+dw_pk_kernel(const DwPk a, const float* __restrict__ wp) {
+    constexpr int NH = GATE ? 2 : 1;
     const int cb = blockIdx.y, b = blockIdx.z;
+    // the taps are the same for the whole block: scalar loads, scalar registers
+    const float* wl[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) wl[h] = wp + (cb + h * a.gate_off) * 80;
+    const int W2 = a.W >> 1;
     const int t = blockIdx.x * 256 + threadIdx.x;
-    const int strip = t / a.W, x = t % a.W;
+    const int strip = t / W2, x0 = (t % W2) * 2;
     const int y0 = strip * a.rows;
     if (y0 >= a.H) return;
     const int y1 = y0 + a.rows < a.H ? y0 + a.rows : a.H;
-    constexpr int NH = GATE ? 2 : 1;
     const int64_t N = (int64_t)a.H * a.W;
     const u32x4* X[NH];
-    const float* Wt[NH];
 #pragma unroll
-    for (int h = 0; h < NH; ++h) {
-        const int c = cb + h * a.gate_off;
-        X[h] = reinterpret_cast<const u32x4*>(a.x + (int64_t)b * a.x_bs) + (int64_t)c * N;
-        Wt[h] = a.wp + c * 80;
-    }
+    for (int h = 0; h < NH; ++h)
+        X[h] = reinterpret_cast<const u32x4*>(a.x + (int64_t)b * a.x_bs) + (int64_t)(cb + h * a.gate_off) * N;
     u32x4* Y = reinterpret_cast<u32x4*>(a.y + (int64_t)b * a.y_bs) + (int64_t)cb * N;
-    float acc[NH][3][8];
+    const bool hasl = x0 > 0, hasr = x0 + 2 < a.W;
+    const int xl = hasl ? x0 - 1 : x0, xr = hasr ? x0 + 2 : x0 + 1;
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+
+    auto fetch = [&](u32x4 (&dst)[NH][4], int i) {
+        const bool rv = i >= 0 && i < a.H;
+        const int64_t ro = (int64_t)(rv ? i : y0) * a.W;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            const u32x4* row = X[h] + ro;
+            const u32x4 c0 = row[xl], c1 = row[x0], c2 = row[x0 + 1], c3 = row[xr];
+            dst[h][0] = rv && hasl ? c0 : zero;
+            dst[h][1] = rv ? c1 : zero;
+            dst[h][2] = rv ? c2 : zero;
+            dst[h][3] = rv && hasr ? c3 : zero;
+        }
+    };
+    float acc[NH][2][3][8];
 #pragma unroll
     for (int h = 0; h < NH; ++h)
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+        for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[h][r][j] = 0.f;
-    const bool hasl = x > 0, hasr = x + 1 < a.W;
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[h][q][r][j] = 0.f;
+    u32x4 cur[NH][4], nxt[NH][4];
+    fetch(cur, y0 - 1);
     for (int i = y0 - 1; i <= y1; ++i) {
-        if (i >= 0 && i < a.H) {
+        fetch(nxt, i + 1 <= y1 ? i + 1 : y1);
 #pragma unroll
-            for (int h = 0; h < NH; ++h) {
-                const u32x4* row = X[h] + (int64_t)i * a.W + x;
-                const u32x4 z = {0u, 0u, 0u, 0u};
-                const u32x4 wl = hasl ? row[-1] : z, wm = row[0], wr = hasr ? row[1] : z;
-                float l[8], m[8], r[8];
-                unpack8(wl, l); unpack8(wm, m); unpack8(wr, r);
-                // input row i is row dy of the window of output row i + 1 - dy; acc[h][dy] collects that output row
+        for (int h = 0; h < NH; ++h) {
+            float c[4][8];
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy)
+            for (int k = 0; k < 4; ++k) unpack8(cur[h][k], c[k]);
+            // input row i is row dy of the window of output row i + 1 - dy; acc[..][dy] collects that output row
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                float w3[3][8];
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) w3[k][j] = wl[h][dy * 24 + k * 8 + j];
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
-                        acc[h][dy][j] = fmaf(Wt[h][(dy * 3 + 0) * 8 + j], l[j],
-                                        fmaf(Wt[h][(dy * 3 + 1) * 8 + j], m[j],
-                                        fmaf(Wt[h][(dy * 3 + 2) * 8 + j], r[j], acc[h][dy][j])));
+                        acc[h][q][dy][j] = fmaf(w3[0][j], c[q][j], fmaf(w3[1][j], c[q + 1][j], fmaf(w3[2][j], c[q + 2][j], acc[h][q][dy][j])));
             }
         }
-        // output row i - 1 is complete (it has seen input rows i-2, i-1, i): it sits in acc[.][2]
+        // output row i - 1 has seen input rows i-2, i-1, i: it sits in acc[..][2]
         const int yo = i - 1;
         if (yo >= y0) {
-            float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float d0 = acc[0][2][j] + Wt[0][72 + j];
-                if (GATE) v[j] = pk_gelu(d0) * (acc[NH - 1][2][j] + Wt[NH - 1][72 + j]);
-                else v[j] = d0;
+            for (int q = 0; q < 2; ++q) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float d0 = acc[0][q][2][j] + wl[0][72 + j];
+                    if (GATE) v[j] = pk_gelu(d0) * (acc[NH - 1][q][2][j] + wl[NH - 1][72 + j]);
+                    else v[j] = d0;
+                }
+                Y[(int64_t)yo * a.W + x0 + q] = pack8(v);
             }
-            Y[(int64_t)yo * a.W + x] = pack8(v);
         }
 #pragma unroll
         for (int h = 0; h < NH; ++h)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { acc[h][2][j] = acc[h][1][j]; acc[h][1][j] = acc[h][0][j]; acc[h][0][j] = 0.f; }
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { acc[h][q][2][j] = acc[h][q][1][j]; acc[h][q][1][j] = acc[h][q][0][j]; acc[h][q][0][j] = 0.f; }
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cur[h][k] = nxt[h][k];
     }
 }
 
 int dw_pk_launch(DwPk a, hipStream_t stream) {
     RST_REQUIRE(a.x && a.wp && a.y, "bf16 depthwise: null operand");
     RST_REQUIRE(aligned16(a.x) && aligned16(a.y), "bf16 depthwise: operands must be 16-byte aligned");
-    a.rows = a.H >= 64 ? 16 : 8;
+    RST_REQUIRE(a.W % 2 == 0 && a.W >= 2, "bf16 depthwise: width %d must be even", a.W);
+    RST_REQUIRE(a.B <= 65535 && a.Cb_out <= 65535, "bf16 depthwise: batch or channel count exceeds 65535");
+    // rows per strip: long strips re-read fewer halo rows; short ones give the chip enough threads
+    a.rows = 32;
+    while (a.rows > 4 && (int64_t)a.B * a.Cb_out * cdiv(a.H, a.rows) * (a.W / 2) < 256 * 256 * 4) a.rows >>= 1;
     if (a.rows > a.H) a.rows = a.H;
     const int strips = (int)cdiv(a.H, a.rows);
-    const dim3 grid((unsigned)cdiv((int64_t)a.W * strips, 256), a.Cb_out, a.B);
+    const dim3 grid((unsigned)cdiv((int64_t)(a.W / 2) * strips, 256), a.Cb_out, a.B);
     const double el = (double)a.B * a.Cb_out * 8 * a.H * a.W;
     if (a.gate_off > 0) {
         ProfScope prof(stream, "pk_dw_gate", el * 50.0, el * 2.0 * 3.0);
-        hipLaunchKernelGGL(dw_pk_kernel<true>, grid, dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(dw_pk_kernel<true>, grid, dim3(256), 0, stream, a, a.wp);
     } else {
         ProfScope prof(stream, "pk_dw", el * 18.0, el * 2.0 * 2.0);
-        hipLaunchKernelGGL(dw_pk_kernel<false>, grid, dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(dw_pk_kernel<false>, grid, dim3(256), 0, stream, a, a.wp);
     }
     RST_LAUNCH_CHECK();
     return RST_OK;

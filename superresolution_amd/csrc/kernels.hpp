@@ -150,7 +150,7 @@ struct GemmPk {
     int K;                               // real input channels (divisor of the LayerNorm statistics)
     int Kb, Mb;                          // channel blocks in / out
     int B; int64_t N;
-    int ngroups, nchunks; int64_t chunk_px;   // filled by the launcher
+    int pb, ngroups, nchunks; int64_t chunk_px;   // filled by the launcher (pb: pairs of row tiles per block)
 };
 int gemm_pk_pairs(int Kb, int Mb);
 int gemm_pk_ks(int Kb);                  // k-steps of 32 channels the kernel for Kb runs (padded), -1: unsupported
