@@ -272,10 +272,19 @@ int rst_bf16_conv1x1_fwd(const void* x_packed, const float* weight, const float*
                          void* workspace, size_t workspace_bytes, void* stream);
 /* TransformerBlock.forward, model/Restromer.py:163-167, on a packed tensor;      */
 /* y may alias x.  C % 8 == 0, C / heads a multiple of 16 (<= 192), C and hidden  */
-/* at most 480.  Returns 0 bytes / RST_ERR_INVALID for unsupported shapes.        */
+/* at most 480, W even.  Returns 0 bytes / RST_ERR_INVALID for unsupported shapes. */
+/* The convolution weights enter the kernels in a prepared form (LayerNorm scale   */
+/* folded in, bf16, matrix-operand order; model/Restromer.py:110-125,80-97 hold    */
+/* the originals).  rst_bf16_block_prepare writes it into a caller-owned device     */
+/* buffer of rst_bf16_block_prepared_bytes (depends on C, heads, hidden and the     */
+/* flags only, not on B, H, W); it stays valid until a parameter changes.  With     */
+/* prepared == NULL rst_bf16_block_fwd prepares into its workspace on every call.   */
+size_t rst_bf16_block_prepared_bytes(const rst_block_desc* desc);
+int rst_bf16_block_prepare(const rst_block_desc* desc, const rst_block_params* params,
+                           void* prepared, void* stream);
 size_t rst_bf16_block_workspace_bytes(const rst_block_desc* desc);
 int rst_bf16_block_fwd(const rst_block_desc* desc, const rst_block_params* params,
-                       const void* x_packed, void* y_packed,
+                       const void* prepared, const void* x_packed, void* y_packed,
                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- */

@@ -89,8 +89,28 @@ def conv1x1(p: Packed, weight: torch.Tensor, bias: Optional[torch.Tensor] = None
     return Packed(out, Cout)
 
 
-def block_(p: Packed, heads: int, hidden: int, params: Dict[str, Optional[torch.Tensor]]) -> Packed:
-    """TransformerBlock (reference: model/Restromer.py:163-167) applied in place to a packed tensor."""
+class PreparedCache:
+    """Prepared weights of one block (rst_bf16_block_prepare), rebuilt when a parameter tensor is replaced or
+    modified in place (torch bumps ``_version`` on every in-place write)."""
+    __slots__ = ("key", "blob")
+
+    def __init__(self):
+        self.key, self.blob = None, None
+
+    def get(self, lib, desc, par, params, device):
+        key = tuple((n, t.data_ptr(), t._version) for n, t in params.items() if t is not None) + (str(device),)
+        if key != self.key:
+            nb = lib.rst_bf16_block_prepared_bytes(ctypes.byref(desc))
+            blob = torch.empty(nb, dtype=torch.uint8, device=device)
+            check(lib.rst_bf16_block_prepare(ctypes.byref(desc), ctypes.byref(par), _ptr(blob), _stream()), "rst_bf16_block_prepare")
+            self.key, self.blob = key, blob
+        return self.blob
+
+
+def block_(p: Packed, heads: int, hidden: int, params: Dict[str, Optional[torch.Tensor]],
+           cache: Optional[PreparedCache] = None) -> Packed:
+    """TransformerBlock (reference: model/Restromer.py:163-167) applied in place to a packed tensor.  With a
+    `cache` the prepared weights are kept between calls."""
     lib = _lib.load()
     B, C, H, W = p.shape
     tensors = {n: _f32(params.get(n), n) for n in PARAM_FIELDS}
@@ -99,9 +119,13 @@ def block_(p: Packed, heads: int, hidden: int, params: Dict[str, Optional[torch.
     if nb == 0:
         raise RuntimeError("bf16 block: " + lib.rst_last_error().decode("utf-8", "replace"))
     par = _fill(BlockParams(), tensors)
+    prepared = None
+    if cache is not None:
+        # keyed on the module's own parameter tensors (the fp32 views above are the same objects for fp32 models)
+        prepared = cache.get(lib, desc, par, {n: params.get(n) for n in PARAM_FIELDS}, p.data.device)
     ws = workspace(nb, p.data.device)
-    check(lib.rst_bf16_block_fwd(ctypes.byref(desc), ctypes.byref(par), _ptr(p.data), _ptr(p.data), _ptr(ws), ws.numel(),
-                                 _stream()), "rst_bf16_block_fwd")
+    check(lib.rst_bf16_block_fwd(ctypes.byref(desc), ctypes.byref(par), _ptr(prepared), _ptr(p.data), _ptr(p.data), _ptr(ws),
+                                 ws.numel(), _stream()), "rst_bf16_block_fwd")
     return p
 
 

@@ -88,27 +88,56 @@ GemmPk pk_gemm_args(const PkWeight& w, const bf16_t* x, int64_t x_bs, bf16_t* y,
 
 static PkWeight pk_plain_weight(int M, int K) { return pk_weight_shape(M, K, NOSEG, NOSEG); }
 
+// the part that depends on the parameters only (channel counts, not B, H, W): may be prepared once and kept
+static void pk_block_carve_prepared(const rst_block_desc* d, Carve& cv, PkBlockBufs& b) {
+    const int C = d->C, Hd = d->hidden, Hp = pad8(Hd);
+    b.wqkv = pk_plain_weight(3 * C, C);
+    b.wpin = pk_weight_shape(2 * Hd, C, Hd, Hp);
+    b.wpout = pk_plain_weight(C, Hd);
+    pk_weight_carve(b.wqkv, cv, 1);
+    pk_weight_carve(b.wpin, cv, 1);
+    pk_weight_carve(b.wpout, cv, 1);
+    b.dw_qkv = cv.floats((size_t)(3 * C / 8) * 80);
+    b.dw_ffn = cv.floats((size_t)(2 * Hp / 8) * 80);
+}
+static size_t pk_block_prepared_bytes(const rst_block_desc* d) {
+    Carve cv(nullptr); PkBlockBufs b{};
+    pk_block_carve_prepared(d, cv, b);
+    return cv.total();
+}
 static void pk_block_carve(const rst_block_desc* d, Carve& cv, PkBlockBufs& b);
 
 static size_t pk_block_ws_bytes(const rst_block_desc* d) {
     Carve cv(nullptr); PkBlockBufs b{};
+    cv.bytes(pk_block_prepared_bytes(d));
     pk_block_carve(d, cv, b);
     return cv.total();
+}
+
+static int pk_block_prepare(const rst_block_desc* d, const rst_block_params* p, const PkBlockBufs& b, hipStream_t stream) {
+    RST_REQUIRE(p, "bf16 block: null parameters");
+    RST_REQUIRE(p->norm1_weight && p->norm2_weight, "bf16 block: null LayerNorm weight");
+    RST_REQUIRE(!d->ln_with_bias || (p->norm1_bias && p->norm2_bias), "bf16 block: ln_with_bias set but a bias is null");
+    RST_REQUIRE(p->temperature && p->qkv_weight && p->qkv_dw_weight && p->proj_weight, "bf16 block: null attention parameter");
+    RST_REQUIRE(p->pin_weight && p->ffn_dw_weight && p->pout_weight, "bf16 block: null feed-forward parameter");
+    RST_REQUIRE(!d->conv_bias || (p->qkv_bias && p->qkv_dw_bias && p->proj_bias && p->pin_bias && p->ffn_dw_bias && p->pout_bias),
+                "bf16 block: conv_bias set but a bias is null");
+    const int C = d->C, Hd = d->hidden, Hp = pad8(Hd);
+    const bool cb = d->conv_bias != 0;
+    RST_TRY(pk_weight_prepare(b.wqkv, p->qkv_weight, p->norm1_weight, d->ln_with_bias ? p->norm1_bias : nullptr,
+                              cb ? p->qkv_bias : nullptr, stream));
+    RST_TRY(pk_prep_dw_launch(p->qkv_dw_weight, cb ? p->qkv_dw_bias : nullptr, 3 * C, NOSEG, NOSEG, 3 * C / 8, b.dw_qkv, stream));
+    RST_TRY(pk_weight_prepare(b.wpin, p->pin_weight, p->norm2_weight, d->ln_with_bias ? p->norm2_bias : nullptr,
+                              cb ? p->pin_bias : nullptr, stream));
+    RST_TRY(pk_prep_dw_launch(p->ffn_dw_weight, cb ? p->ffn_dw_bias : nullptr, 2 * Hd, Hd, Hp, 2 * Hp / 8, b.dw_ffn, stream));
+    return pk_weight_prepare(b.wpout, p->pout_weight, nullptr, nullptr, cb ? p->pout_bias : nullptr, stream);
 }
 
 static void pk_block_carve(const rst_block_desc* d, Carve& cv, PkBlockBufs& b) {
     const int C = d->C, Hd = d->hidden, Hp = pad8(Hd), heads = d->heads, c = C / heads, B = d->B;
     const int64_t N = (int64_t)d->H * d->W;
-    b.wqkv = pk_plain_weight(3 * C, C);
     b.wattn = pk_plain_weight(C, C);
-    b.wpin = pk_weight_shape(2 * Hd, C, Hd, Hp);
-    b.wpout = pk_plain_weight(C, Hd);
-    pk_weight_carve(b.wqkv, cv, 1);
     pk_weight_carve(b.wattn, cv, B);
-    pk_weight_carve(b.wpin, cv, 1);
-    pk_weight_carve(b.wpout, cv, 1);
-    b.dw_qkv = cv.floats((size_t)(3 * C / 8) * 80);
-    b.dw_ffn = cv.floats((size_t)(2 * Hp / 8) * 80);
     const int w1 = 3 * C > 2 * Hp ? 3 * C : 2 * Hp, w2 = 3 * C > Hp ? 3 * C : Hp;
     b.buf1 = cv.halves((size_t)B * w1 * N);
     b.buf2 = cv.halves((size_t)B * w2 * N);
@@ -125,15 +154,11 @@ static void pk_block_carve(const rst_block_desc* d, Carve& cv, PkBlockBufs& b) {
 }
 
 // x1 = x + attention(LN1(x));  y = x1 + ffn(LN2(x1))   (model/Restromer.py:163-167), y may alias x
-static int pk_block_fwd(const rst_block_desc* d, const rst_block_params* p, const bf16_t* x, bf16_t* y,
+static int pk_block_fwd(const rst_block_desc* d, const rst_block_params* p, const void* prepared, const bf16_t* x, bf16_t* y,
                         void* ws, size_t ws_bytes, hipStream_t stream) {
     RST_REQUIRE(x && y && p, "bf16 block: null operand");
-    RST_REQUIRE(p->norm1_weight && p->norm2_weight, "bf16 block: null LayerNorm weight");
-    RST_REQUIRE(!d->ln_with_bias || (p->norm1_bias && p->norm2_bias), "bf16 block: ln_with_bias set but a bias is null");
-    RST_REQUIRE(p->temperature && p->qkv_weight && p->qkv_dw_weight && p->proj_weight, "bf16 block: null attention parameter");
-    RST_REQUIRE(p->pin_weight && p->ffn_dw_weight && p->pout_weight, "bf16 block: null feed-forward parameter");
-    RST_REQUIRE(!d->conv_bias || (p->qkv_bias && p->qkv_dw_bias && p->proj_bias && p->pin_bias && p->ffn_dw_bias && p->pout_bias),
-                "bf16 block: conv_bias set but a bias is null");
+    RST_REQUIRE(p->temperature && p->proj_weight, "bf16 block: null attention parameter");
+    RST_REQUIRE(!d->conv_bias || p->proj_bias, "bf16 block: conv_bias set but a bias is null");
     if (ws == nullptr || ws_bytes < pk_block_ws_bytes(d))
         return fail(RST_ERR_WORKSPACE, "bf16 block: workspace %zu < %zu bytes", ws_bytes, pk_block_ws_bytes(d));
     const int C = d->C, Hd = d->hidden, Hp = pad8(Hd), heads = d->heads, c = C / heads, B = d->B;
@@ -142,19 +167,22 @@ static int pk_block_fwd(const rst_block_desc* d, const rst_block_params* p, cons
     const bool cb = d->conv_bias != 0;
     const int ln_mode = d->ln_with_bias ? 1 : 2;
     Carve cv(ws); PkBlockBufs b{};
+    {
+        void* own = cv.bytes(pk_block_prepared_bytes(d));
+        Carve cp(prepared ? const_cast<void*>(prepared) : own);
+        pk_block_carve_prepared(d, cp, b);
+        if (!prepared) RST_TRY(pk_block_prepare(d, p, b, stream));
+    }
     pk_block_carve(d, cv, b);
     bf16_t* t = b.buf1; bf16_t* qkv = b.buf2; bf16_t* u = b.buf1; bf16_t* gbuf = b.buf2;
     const int64_t cn = (int64_t)C * N;
 
     // ---- MDTA (model/Restromer.py:128-150) ----
-    RST_TRY(pk_weight_prepare(b.wqkv, p->qkv_weight, p->norm1_weight, d->ln_with_bias ? p->norm1_bias : nullptr,
-                              cb ? p->qkv_bias : nullptr, stream));
     {
         GemmPk g = pk_gemm_args(b.wqkv, x, cn, t, 3 * cn, B, N);
         g.ln_mode = ln_mode; g.ln_s = b.wqkv.s; g.ln_c = b.wqkv.c;
         RST_TRY(gemm_pk_launch(g, stream));
     }
-    RST_TRY(pk_prep_dw_launch(p->qkv_dw_weight, cb ? p->qkv_dw_bias : nullptr, 3 * C, big, big, 3 * C / 8, b.dw_qkv, stream));
     {
         DwPk a{};
         a.x = t; a.x_bs = 3 * cn; a.wp = b.dw_qkv; a.y = qkv; a.y_bs = 3 * cn;
@@ -190,21 +218,17 @@ static int pk_block_fwd(const rst_block_desc* d, const rst_block_params* p, cons
         RST_TRY(gemm_pk_launch(g, stream));
     }
     // ---- GDFN (model/Restromer.py:99-104) ----
-    RST_TRY(pk_weight_prepare(b.wpin, p->pin_weight, p->norm2_weight, d->ln_with_bias ? p->norm2_bias : nullptr,
-                              cb ? p->pin_bias : nullptr, stream));
     {
         GemmPk g = pk_gemm_args(b.wpin, y, cn, u, (int64_t)2 * Hp * N, B, N);
         g.ln_mode = ln_mode; g.ln_s = b.wpin.s; g.ln_c = b.wpin.c;
         RST_TRY(gemm_pk_launch(g, stream));
     }
-    RST_TRY(pk_prep_dw_launch(p->ffn_dw_weight, cb ? p->ffn_dw_bias : nullptr, 2 * Hd, Hd, Hp, 2 * Hp / 8, b.dw_ffn, stream));
     {
         DwPk a{};
         a.x = u; a.x_bs = (int64_t)2 * Hp * N; a.wp = b.dw_ffn; a.y = gbuf; a.y_bs = (int64_t)Hp * N;
         a.B = B; a.Cb_out = Hp / 8; a.H = d->H; a.W = d->W; a.gate_off = Hp / 8;
         RST_TRY(dw_pk_launch(a, stream));
     }
-    RST_TRY(pk_weight_prepare(b.wpout, p->pout_weight, nullptr, nullptr, cb ? p->pout_bias : nullptr, stream));
     {
         GemmPk g = pk_gemm_args(b.wpout, gbuf, (int64_t)Hp * N, y, cn, B, N);
         g.R = y; g.r_bs = cn;
@@ -259,10 +283,18 @@ int rst_bf16_conv1x1_fwd(const void* x_packed, const float* weight, const float*
 }
 
 size_t rst_bf16_block_workspace_bytes(const rst_block_desc* d) { return check_pk_desc(d) == RST_OK ? pk_block_ws_bytes(d) : 0; }
-int rst_bf16_block_fwd(const rst_block_desc* d, const rst_block_params* p, const void* x_packed, void* y_packed,
+size_t rst_bf16_block_prepared_bytes(const rst_block_desc* d) { return check_pk_desc(d) == RST_OK ? pk_block_prepared_bytes(d) : 0; }
+int rst_bf16_block_prepare(const rst_block_desc* d, const rst_block_params* p, void* prepared, void* stream) {
+    RST_TRY(check_pk_desc(d));
+    RST_REQUIRE(prepared != nullptr && aligned16(prepared), "bf16 block: prepared buffer null or misaligned");
+    Carve cp(prepared); PkBlockBufs b{};
+    pk_block_carve_prepared(d, cp, b);
+    return pk_block_prepare(d, p, b, static_cast<hipStream_t>(stream));
+}
+int rst_bf16_block_fwd(const rst_block_desc* d, const rst_block_params* p, const void* prepared, const void* x_packed, void* y_packed,
                        void* workspace, size_t workspace_bytes, void* stream) {
     RST_TRY(check_pk_desc(d));
-    return pk_block_fwd(d, p, static_cast<const bf16_t*>(x_packed), static_cast<bf16_t*>(y_packed), workspace, workspace_bytes,
+    return pk_block_fwd(d, p, prepared, static_cast<const bf16_t*>(x_packed), static_cast<bf16_t*>(y_packed), workspace, workspace_bytes,
                         static_cast<hipStream_t>(stream));
 }
 

@@ -72,25 +72,26 @@ pk_prep_a_kernel(const float* __restrict__ w, int64_t w_bs, int ldw, const float
 }
 
 // s[pos] = sum_k bf16(w[ch][k] gamma[k]) (the rounded values, so that the mean term cancels what the product adds);
-// c[pos] = sum_k w[ch][k] beta[k] + bias[ch];  zero at padding positions.  One thread per position.
+// c[pos] = sum_k w[ch][k] beta[k] + bias[ch];  zero at padding positions.  One wave per position.
 __global__ void __launch_bounds__(256)
 pk_prep_sc_kernel(const float* __restrict__ w, int ldw, const float* __restrict__ gamma, const float* __restrict__ beta,
                   const float* __restrict__ bias, int M, int K, int seg, int seg_pad, int npos,
                   float* __restrict__ s, float* __restrict__ c) {
-    const int pos = blockIdx.x * 256 + threadIdx.x;
+    const int pos = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (pos >= npos) return;
     const int ch = src_channel(pos, seg, seg_pad, M);
     float ss = 0.f, cc = 0.f;
     if (ch >= 0) {
-        for (int k = 0; k < K; ++k) {
+        for (int k = lane; k < K; k += 64) {
             const float x = w[(int64_t)ch * ldw + k];
             if (gamma != nullptr) ss += bf_lo(to_bf16_bits(x * gamma[k]));
             if (beta != nullptr) cc = fmaf(x, beta[k], cc);
         }
+        ss = wave_sum(ss);
+        cc = wave_sum(cc);
         if (bias != nullptr) cc += bias[ch];
     }
-    s[pos] = ss;
-    c[pos] = cc;
+    if (lane == 0) { s[pos] = ss; c[pos] = cc; }
 }
 
 // depthwise weights per channel block: 72 taps [tap][8 channels] + 8 biases
@@ -116,7 +117,7 @@ int pk_prep_a_launch(const float* w, int64_t w_bs, int ldw, const float* gamma, 
 }
 int pk_prep_sc_launch(const float* w, int ldw, const float* gamma, const float* beta, const float* bias, int M, int K,
                       int seg, int seg_pad, int npos, float* s, float* c, hipStream_t stream) {
-    hipLaunchKernelGGL(pk_prep_sc_kernel, dim3((unsigned)cdiv(npos, 256)), dim3(256), 0, stream, w, ldw, gamma, beta, bias,
+    hipLaunchKernelGGL(pk_prep_sc_kernel, dim3((unsigned)cdiv(npos, 4)), dim3(256), 0, stream, w, ldw, gamma, beta, bias,
                        M, K, seg, seg_pad, npos, s, c);
     RST_LAUNCH_CHECK();
     return RST_OK;

@@ -246,7 +246,9 @@ class Restormer(nn.Module):
 
         def stage(p, blocks):
             for blk in blocks:
-                pk.block_(p, blk.attn.num_heads, blk.ffn.hidden_features, blk._params())
+                if getattr(blk, "_pk_cache", None) is None:
+                    blk._pk_cache = pk.PreparedCache()
+                pk.block_(p, blk.attn.num_heads, blk.ffn.hidden_features, blk._params(), blk._pk_cache)
             return p
 
         def down(p, mod):
@@ -286,7 +288,7 @@ class Restormer(nn.Module):
         if inp_img.shape[-2] % 8 or inp_img.shape[-1] % 8:
             raise RuntimeError(f"Restormer needs H and W divisible by 8, got {tuple(inp_img.shape[-2:])}")
         if inp_img.dtype == torch.bfloat16 or (inp_img.is_cuda and torch.is_autocast_enabled()
-                                               and torch.get_autocast_gpu_dtype() == torch.bfloat16):
+                                               and torch.get_autocast_dtype("cuda") == torch.bfloat16):
             return self._forward_bf16(inp_img)
         e1_in = self.patch_embed(inp_img)
         e1 = self.encoder_level1(e1_in)

@@ -141,3 +141,32 @@ def test_bf16_path_refuses_training_and_cpu():
         net(torch.rand(1, 3, 16, 16, device="cuda").bfloat16())      # grad mode on
     with pytest.raises(RuntimeError):
         bf16.pack(torch.rand(1, 8, 4, 4))                             # CPU tensor
+
+
+def test_prepared_weights_cache_follows_parameter_updates():
+    """Prepared weights kept between calls give the same bits as preparing on every call, and are rebuilt
+    after an in-place parameter update."""
+    from superresolution_amd import bf16
+    from superresolution_amd.model.Restromer import TransformerBlock
+    case = BF16_BLOCK_CASES[2]
+    tag, dim, heads, ln_type, bias, b, h, w = case
+    sd, x, r = recipe.block_case_tensors(case, torch.float32)
+    blk = TransformerBlock(dim, heads, recipe.FFN_FACTOR, bias, ln_type)
+    blk.load_state_dict(sd, strict=True)
+    blk = blk.cuda()
+    cache = bf16.PreparedCache()
+
+    def run(c):
+        with torch.no_grad():
+            p = bf16.pack(x.cuda())
+            bf16.block_(p, heads, blk.ffn.hidden_features, blk._params(), c)
+            return p.data.clone()
+    first = run(cache)
+    assert torch.equal(first.view(torch.int16), run(None).view(torch.int16))
+    assert torch.equal(first.view(torch.int16), run(cache).view(torch.int16))
+    with torch.no_grad():
+        blk.attn.qkv.weight.mul_(1.5)
+        blk.norm2.body.weight.add_(0.25)
+    changed = run(cache)
+    assert not torch.equal(changed.view(torch.int16), first.view(torch.int16))
+    assert torch.equal(changed.view(torch.int16), run(None).view(torch.int16))
