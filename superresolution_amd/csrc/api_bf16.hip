@@ -35,7 +35,7 @@ PkWeight pk_weight_shape(int M, int K, int seg, int seg_pad) {
     w.K = K; w.M = M; w.seg = seg; w.seg_pad = seg_pad;
     const int nseg = (int)cdiv(M, seg);
     w.Kb = (int)cdiv(K, 8);
-    w.Mb = seg_pad >= NOSEG ? (int)cdiv(M, 8) : nseg * seg_pad / 8;
+    w.Mb = seg_pad >= NOSEG ? (int)cdiv(M, 8) : seg_pad < 0 ? 2 * pad8(seg) / 8 : nseg * seg_pad / 8;
     w.KS = gemm_pk_ks(w.Kb);
     w.P = gemm_pk_pairs(w.Kb, w.Mb);
     w.ngroups = (int)cdiv(cdiv(w.Mb, 4), w.P);
@@ -92,7 +92,7 @@ static PkWeight pk_plain_weight(int M, int K) { return pk_weight_shape(M, K, NOS
 static void pk_block_carve_prepared(const rst_block_desc* d, Carve& cv, PkBlockBufs& b) {
     const int C = d->C, Hd = d->hidden, Hp = pad8(Hd);
     b.wqkv = pk_plain_weight(3 * C, C);
-    b.wpin = pk_weight_shape(2 * Hd, C, Hd, Hp);
+    b.wpin = pk_weight_shape(2 * Hd, C, Hd, -1);       // x1 / x2 interleaved in fours
     b.wpout = pk_plain_weight(C, Hd);
     pk_weight_carve(b.wqkv, cv, 1);
     pk_weight_carve(b.wpin, cv, 1);
@@ -129,7 +129,7 @@ static int pk_block_prepare(const rst_block_desc* d, const rst_block_params* p, 
     RST_TRY(pk_prep_dw_launch(p->qkv_dw_weight, cb ? p->qkv_dw_bias : nullptr, 3 * C, NOSEG, NOSEG, 3 * C / 8, b.dw_qkv, stream));
     RST_TRY(pk_weight_prepare(b.wpin, p->pin_weight, p->norm2_weight, d->ln_with_bias ? p->norm2_bias : nullptr,
                               cb ? p->pin_bias : nullptr, stream));
-    RST_TRY(pk_prep_dw_launch(p->ffn_dw_weight, cb ? p->ffn_dw_bias : nullptr, 2 * Hd, Hd, Hp, 2 * Hp / 8, b.dw_ffn, stream));
+    RST_TRY(pk_prep_dw_launch(p->ffn_dw_weight, cb ? p->ffn_dw_bias : nullptr, 2 * Hd, Hd, -1, 2 * Hp / 8, b.dw_ffn, stream));
     return pk_weight_prepare(b.wpout, p->pout_weight, nullptr, nullptr, cb ? p->pout_bias : nullptr, stream);
 }
 
@@ -186,7 +186,7 @@ static int pk_block_fwd(const rst_block_desc* d, const rst_block_params* p, cons
     {
         DwPk a{};
         a.x = t; a.x_bs = 3 * cn; a.wp = b.dw_qkv; a.y = qkv; a.y_bs = 3 * cn;
-        a.B = B; a.Cb_out = 3 * C / 8; a.H = d->H; a.W = d->W; a.gate_off = 0;
+        a.B = B; a.Cb = 3 * C / 8; a.H = d->H; a.W = d->W; a.gate = 0;
         RST_TRY(dw_pk_launch(a, stream));
     }
     {
@@ -226,7 +226,7 @@ static int pk_block_fwd(const rst_block_desc* d, const rst_block_params* p, cons
     {
         DwPk a{};
         a.x = u; a.x_bs = (int64_t)2 * Hp * N; a.wp = b.dw_ffn; a.y = gbuf; a.y_bs = (int64_t)Hp * N;
-        a.B = B; a.Cb_out = Hp / 8; a.H = d->H; a.W = d->W; a.gate_off = Hp / 8;
+        a.B = B; a.Cb = 2 * Hp / 8; a.H = d->H; a.W = d->W; a.gate = 1;
         RST_TRY(dw_pk_launch(a, stream));
     }
     {

@@ -38,7 +38,14 @@ __device__ __forceinline__ uint16_t to_bf16_bits(float x) { return (uint16_t)(pa
 
 // Position p of a packed buffer -> channel of the source tensor, or -1 for padding.  The source channels come in
 // segments of `seg` channels, each padded to `seg_pad` positions (the two halves of the gated feed-forward).
+// seg_pad < 0: two segments interleaved in groups of four -- block j of 8 positions holds channels 4j..4j+3 of the
+// first segment and then the same channels of the second (the gated feed-forward: a lane that owns one block has
+// both factors of gelu(x1) * x2).
 __device__ __forceinline__ int src_channel(int p, int seg, int seg_pad, int total) {
+    if (seg_pad < 0) {
+        const int i = 4 * (p >> 3) + (p & 3), half = (p >> 2) & 1;
+        return (i < seg && half * seg + i < total) ? half * seg + i : -1;
+    }
     const int q = p / seg_pad, r = p % seg_pad;
     const int ch = q * seg + r;
     return (r < seg && ch < total) ? ch : -1;
@@ -349,107 +356,100 @@ __device__ __forceinline__ float pk_gelu(float x) {
     return x * phi;
 }
 
-// One thread = two neighbouring pixel columns of a strip of rows x 8 channels (x 2 halves when gated).  An input
-// row (four 16-byte chunks: x-1 .. x+2, the next row's already in flight) adds to the three output rows it
-// touches; finished rows leave as two 16-byte chunks.  The 72 taps + 8 biases of the channel block are the
-// same for the whole block and live in scalar registers.  No branch around a load: out-of-image chunks read a valid address and are zeroed.
-// grid = (ceil(W/2 * strips / 256), Cb_out, B)
-template <bool GATE>
+// One thread = two neighbouring pixel columns of a strip of rows x one block of 8 channels.  An input row (four
+// 16-byte chunks: x-1 .. x+2, the next row's already in flight) adds to the three output rows it touches; the three
+// accumulator sets and the three chunk buffers change roles from row to row (the loop is unrolled by three, nothing
+// is copied).  The 72 taps + 8 biases of the channel block are the same for the whole block and live in scalar
+// registers.  No branch around a load: out-of-image chunks read a valid address and are zeroed.
+// GATE: the block holds 4 channels of x1 and the same 4 channels of x2 (see src_channel); the thread writes
+// gelu(d[0..3]) * d[4..7], 8 bytes per pixel, into its half of the output chunk.
+// grid = (ceil(W/2 * strips / 256), channel blocks, B)
+template <bool GATE, int PX>
 __global__ void __launch_bounds__(256)
 dw_pk_kernel(const DwPk a, const float* __restrict__ wp) {
-    constexpr int NH = GATE ? 2 : 1;
     const int cb = blockIdx.y, b = blockIdx.z;
-    // the taps are the same for the whole block: scalar loads, scalar registers
-    const float* wl[NH];
+    const float* wl = wp + cb * 80;
+    // the taps of the third window row wait in vector registers (all 72 + 8 do not fit the scalar file beside the
+    // rest): the zero the compiler cannot see makes these vector loads
+    float w2[24];
+    {
+        int z;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(z));
 #pragma unroll
-    for (int h = 0; h < NH; ++h) wl[h] = wp + (cb + h * a.gate_off) * 80;
-    const int W2 = a.W >> 1;
+        for (int j = 0; j < 24; ++j) w2[j] = wl[48 + j + z];
+    }
+    const int W2 = a.W / PX;
     const int t = blockIdx.x * 256 + threadIdx.x;
-    const int strip = t / W2, x0 = (t % W2) * 2;
+    const int strip = t / W2, x0 = (t % W2) * PX;
     const int y0 = strip * a.rows;
     if (y0 >= a.H) return;
     const int y1 = y0 + a.rows < a.H ? y0 + a.rows : a.H;
     const int64_t N = (int64_t)a.H * a.W;
-    const u32x4* X[NH];
-#pragma unroll
-    for (int h = 0; h < NH; ++h)
-        X[h] = reinterpret_cast<const u32x4*>(a.x + (int64_t)b * a.x_bs) + (int64_t)(cb + h * a.gate_off) * N;
-    u32x4* Y = reinterpret_cast<u32x4*>(a.y + (int64_t)b * a.y_bs) + (int64_t)cb * N;
-    const bool hasl = x0 > 0, hasr = x0 + 2 < a.W;
-    const int xl = hasl ? x0 - 1 : x0, xr = hasr ? x0 + 2 : x0 + 1;
+    const u32x4* X = reinterpret_cast<const u32x4*>(a.x + (int64_t)b * a.x_bs) + (int64_t)cb * N;
+    bf16_t* Yb = a.y + (int64_t)b * a.y_bs;
+    const bool hasl = x0 > 0, hasr = x0 + PX < a.W;
+    const int xl = hasl ? x0 - 1 : x0, xr = hasr ? x0 + PX : x0 + PX - 1;
     const u32x4 zero = {0u, 0u, 0u, 0u};
 
-    auto fetch = [&](u32x4 (&dst)[NH][4], int i) {
-        const bool rv = i >= 0 && i < a.H;
-        const int64_t ro = (int64_t)(rv ? i : y0) * a.W;
+    // raw chunks only: what is outside the image is zeroed where the row is consumed, so that nothing waits for
+    // the loads here
+    auto fetch = [&](u32x4 (&dst)[PX + 2], int i) {
+        const u32x4* row = X + (int64_t)(i < 0 ? 0 : (i < a.H ? i : a.H - 1)) * a.W;
+        dst[0] = row[xl];
 #pragma unroll
-        for (int h = 0; h < NH; ++h) {
-            const u32x4* row = X[h] + ro;
-            const u32x4 c0 = row[xl], c1 = row[x0], c2 = row[x0 + 1], c3 = row[xr];
-            dst[h][0] = rv && hasl ? c0 : zero;
-            dst[h][1] = rv ? c1 : zero;
-            dst[h][2] = rv ? c2 : zero;
-            dst[h][3] = rv && hasr ? c3 : zero;
-        }
+        for (int q = 0; q < PX; ++q) dst[1 + q] = row[x0 + q];
+        dst[PX + 1] = row[xr];
     };
-    float acc[NH][2][3][8];
-#pragma unroll
-    for (int h = 0; h < NH; ++h)
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[h][q][r][j] = 0.f;
-    u32x4 cur[NH][4], nxt[NH][4];
-    fetch(cur, y0 - 1);
-    for (int i = y0 - 1; i <= y1; ++i) {
+    // input row i is window row 0 of output row i+1 (P, started here), row 1 of output row i (Q) and row 2 of
+    // output row i-1 (R), which is complete after this step
+    auto step = [&](int i, float (&P)[PX][8], float (&Q)[PX][8], float (&R)[PX][8], const u32x4 (&cur)[PX + 2], u32x4 (&nxt)[PX + 2]) {
         fetch(nxt, i + 1 <= y1 ? i + 1 : y1);
+        float c[PX + 2][8];
+        const bool rv = i >= 0 && i < a.H;
 #pragma unroll
-        for (int h = 0; h < NH; ++h) {
-            float c[4][8];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) unpack8(cur[h][k], c[k]);
-            // input row i is row dy of the window of output row i + 1 - dy; acc[..][dy] collects that output row
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                float w3[3][8];
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) w3[k][j] = wl[h][dy * 24 + k * 8 + j];
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        acc[h][q][dy][j] = fmaf(w3[0][j], c[q][j], fmaf(w3[1][j], c[q + 1][j], fmaf(w3[2][j], c[q + 2][j], acc[h][q][dy][j])));
-            }
+        for (int k = 0; k < PX + 2; ++k) {
+            const bool ok = rv && (k > 0 || hasl) && (k < PX + 1 || hasr);
+            unpack8(ok ? cur[k] : zero, c[k]);
         }
-        // output row i - 1 has seen input rows i-2, i-1, i: it sits in acc[..][2]
+#pragma unroll
+        for (int q = 0; q < PX; ++q)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                P[q][j] = fmaf(wl[0 + j], c[q][j], fmaf(wl[8 + j], c[q + 1][j], wl[16 + j] * c[q + 2][j]));
+                Q[q][j] = fmaf(wl[24 + j], c[q][j], fmaf(wl[32 + j], c[q + 1][j], fmaf(wl[40 + j], c[q + 2][j], Q[q][j])));
+                R[q][j] = fmaf(w2[j], c[q][j], fmaf(w2[8 + j], c[q + 1][j], fmaf(w2[16 + j], c[q + 2][j], R[q][j])));
+            }
         const int yo = i - 1;
         if (yo >= y0) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
+            for (int q = 0; q < PX; ++q) {
                 float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float d0 = acc[0][q][2][j] + wl[0][72 + j];
-                    if (GATE) v[j] = pk_gelu(d0) * (acc[NH - 1][q][2][j] + wl[NH - 1][72 + j]);
-                    else v[j] = d0;
+                for (int j = 0; j < 8; ++j) v[j] = R[q][j] + wl[72 + j];
+                const int64_t px = (int64_t)yo * a.W + x0 + q;
+                if (GATE) {
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    u32x2 o;
+                    o[0] = pack_bf16(pk_gelu(v[0]) * v[4], pk_gelu(v[1]) * v[5]);
+                    o[1] = pack_bf16(pk_gelu(v[2]) * v[6], pk_gelu(v[3]) * v[7]);
+                    reinterpret_cast<u32x2*>(Yb)[((int64_t)(cb >> 1) * N + px) * 2 + (cb & 1)] = o;
+                } else {
+                    reinterpret_cast<u32x4*>(Yb)[(int64_t)cb * N + px] = pack8(v);
                 }
-                Y[(int64_t)yo * a.W + x0 + q] = pack8(v);
             }
         }
+    };
+    float A[PX][8], Bq[PX][8], C[PX][8];
 #pragma unroll
-        for (int h = 0; h < NH; ++h)
+    for (int q = 0; q < PX; ++q)
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) { acc[h][q][2][j] = acc[h][q][1][j]; acc[h][q][1][j] = acc[h][q][0][j]; acc[h][q][0][j] = 0.f; }
-#pragma unroll
-        for (int h = 0; h < NH; ++h)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) cur[h][k] = nxt[h][k];
+        for (int j = 0; j < 8; ++j) { A[q][j] = 0.f; Bq[q][j] = 0.f; C[q][j] = 0.f; }
+    u32x4 X0[PX + 2], X1[PX + 2], X2[PX + 2];
+    fetch(X0, y0 - 1);
+    for (int i = y0 - 1; i <= y1; i += 3) {
+        step(i, A, Bq, C, X0, X1);
+        if (i + 1 <= y1) step(i + 1, C, A, Bq, X1, X2);
+        if (i + 2 <= y1) step(i + 2, Bq, C, A, X2, X0);
     }
 }
 
@@ -457,20 +457,25 @@ int dw_pk_launch(DwPk a, hipStream_t stream) {
     RST_REQUIRE(a.x && a.wp && a.y, "bf16 depthwise: null operand");
     RST_REQUIRE(aligned16(a.x) && aligned16(a.y), "bf16 depthwise: operands must be 16-byte aligned");
     RST_REQUIRE(a.W % 2 == 0 && a.W >= 2, "bf16 depthwise: width %d must be even", a.W);
-    RST_REQUIRE(a.B <= 65535 && a.Cb_out <= 65535, "bf16 depthwise: batch or channel count exceeds 65535");
+    RST_REQUIRE(a.B <= 65535 && a.Cb <= 65535, "bf16 depthwise: batch or channel count exceeds 65535");
     // rows per strip: long strips re-read fewer halo rows; short ones give the chip enough threads
-    a.rows = 32;
-    while (a.rows > 4 && (int64_t)a.B * a.Cb_out * cdiv(a.H, a.rows) * (a.W / 2) < 256 * 256 * 4) a.rows >>= 1;
+    // measured on 16 x 96 x 256 x 256: plain 1 pixel per thread / 8-row strips 255 us, 2 pixels / 16 rows 274 us;
+    // gated 237 us and 222 us
+    const int px = a.gate ? 2 : 1;
+    a.rows = a.gate ? 16 : 8;
+    while (a.rows > 4 && (int64_t)a.B * a.Cb * cdiv(a.H, a.rows) * (a.W / px) < 256 * 256 * 4) a.rows >>= 1;
     if (a.rows > a.H) a.rows = a.H;
     const int strips = (int)cdiv(a.H, a.rows);
-    const dim3 grid((unsigned)cdiv((int64_t)(a.W / 2) * strips, 256), a.Cb_out, a.B);
-    const double el = (double)a.B * a.Cb_out * 8 * a.H * a.W;
-    if (a.gate_off > 0) {
-        ProfScope prof(stream, "pk_dw_gate", el * 50.0, el * 2.0 * 3.0);
-        hipLaunchKernelGGL(dw_pk_kernel<true>, grid, dim3(256), 0, stream, a, a.wp);
+    const dim3 grid((unsigned)cdiv((int64_t)(a.W / px) * strips, 256), a.Cb, a.B);
+    const double el = (double)a.B * a.Cb * 8 * a.H * a.W;
+    if (a.gate) {
+        ProfScope prof(stream, "pk_dw_gate", el * 25.0, el * 2.0 * 1.5);
+        if (px == 1) hipLaunchKernelGGL((dw_pk_kernel<true, 1>), grid, dim3(256), 0, stream, a, a.wp);
+        else hipLaunchKernelGGL((dw_pk_kernel<true, 2>), grid, dim3(256), 0, stream, a, a.wp);
     } else {
         ProfScope prof(stream, "pk_dw", el * 18.0, el * 2.0 * 2.0);
-        hipLaunchKernelGGL(dw_pk_kernel<false>, grid, dim3(256), 0, stream, a, a.wp);
+        if (px == 1) hipLaunchKernelGGL((dw_pk_kernel<false, 1>), grid, dim3(256), 0, stream, a, a.wp);
+        else hipLaunchKernelGGL((dw_pk_kernel<false, 2>), grid, dim3(256), 0, stream, a, a.wp);
     }
     RST_LAUNCH_CHECK();
     return RST_OK;

@@ -156,16 +156,18 @@ int gemm_pk_pairs(int Kb, int Mb);
 int gemm_pk_ks(int Kb);                  // k-steps of 32 channels the kernel for Kb runs (padded), -1: unsupported
 int gemm_pk_launch(GemmPk g, hipStream_t stream);
 // source channels come as segments of `seg` channels, each padded to `seg_pad` positions in the packed buffer
+// (seg_pad < 0: two segments interleaved in groups of four channels)
 int pk_prep_a_launch(const float* w, int64_t w_bs, int ldw, const float* gamma, int M, int K, int seg, int seg_pad,
                      int ntiles, int KS, bf16_t* frag, int64_t frag_bs, int nb, hipStream_t stream);
 int pk_prep_sc_launch(const float* w, int ldw, const float* gamma, const float* beta, const float* bias, int M, int K,
                       int seg, int seg_pad, int npos, float* s, float* c, hipStream_t stream);
 int pk_prep_dw_launch(const float* w, const float* bias, int C, int seg, int seg_pad, int Cb, float* out, hipStream_t stream);
-// depthwise 3x3; gate_off > 0: y[cb] = gelu(d[cb]) * d[cb + gate_off]
+// depthwise 3x3 over `Cb` channel blocks.  gate: every block holds 4 channels of x1 and the same 4 of x2 (segments
+// interleaved by the weight preparation, seg_pad < 0); y[4 cb + i] = gelu(d[i]) * d[4 + i], y has Cb / 2 blocks
 struct DwPk {
     const bf16_t* x; int64_t x_bs; const float* wp;   // wp: [Cb][80] from pk_prep_dw_launch
     bf16_t* y; int64_t y_bs;
-    int B, Cb_out, H, W; int gate_off;
+    int B, Cb, H, W; int gate;
     int rows;                            // filled by the launcher
 };
 int dw_pk_launch(DwPk a, hipStream_t stream);
