@@ -105,11 +105,12 @@ def kernel_profile(run_once):
     return json.loads(buf.value.decode())
 
 
-def measured_traffic(name, batch, size, mode):
+def measured_traffic(name, batch, size, mode, dtype="f32"):
     """HBM bytes per launch of kernel group `name`, from the committed rocprofv3 --pmc run of this
-    same workload (profiles/r1_e_hbm_traffic.json; FETCH_SIZE and WRITE_SIZE collected in separate
-    passes, FETCH_SIZE doubled as gfx950 requires).  None for any other workload or kernel."""
-    path = os.path.join(ROOT, "profiles", "r1_e_hbm_traffic.json")
+    same workload (profiles/r1_e_hbm_traffic.json, r1_f_bf16_hbm_traffic.json for --dtype bf16; FETCH_SIZE and
+    WRITE_SIZE collected in separate passes, FETCH_SIZE doubled as gfx950 requires).  None for any other
+    workload or kernel."""
+    path = os.path.join(ROOT, "profiles", "r1_e_hbm_traffic.json" if dtype == "f32" else "r1_f_bf16_hbm_traffic.json")
     try:
         d = json.load(open(path))
     except (OSError, ValueError):
@@ -265,7 +266,7 @@ def main():
         step()          # the profiled extra step on rank 0 contains collectives: every rank takes part
     if rank == 0:
         prof = kernel_profile(step)
-        roof, breakdown, ktotal = roofline_from(prof, lambda name: measured_traffic(name, B, S, args.mode))
+        roof, breakdown, ktotal = roofline_from(prof, lambda name: measured_traffic(name, B, S, args.mode, args.dtype))
         out["roofline"] = roof
         out["kernels"] = breakdown
         out["hip_kernel_ms_per_step"] = round(ktotal, 3)

@@ -2,7 +2,7 @@
 """Turn rocprofv3 --pmc counter_collection.csv files of one bench.py run into the per-kernel-group
 JSON files kept under profiles/.
 
-usage: summarize_pmc.py traffic <fetch.csv> <write.csv> <out.json>
+usage: summarize_pmc.py traffic <fetch.csv> <write.csv> <out.json> [workload description]
        summarize_pmc.py mfma <counters.csv> <out.json>
 Kernel groups are the names bench.py's in-library profiler uses."""
 import collections
@@ -24,6 +24,14 @@ def group(name):
     k, args = m.group(1), [a.strip() for a in m.group(2).split(",")]
     if k in ("gemm_nn_res_kernel", "gemm_nn_dma_kernel"):
         return "gemm_nn_ln" if args[3] == "true" else "gemm_nn"
+    if k == "gemm_pk_kernel":
+        return "pk_gemm_ln" if args[2] == "true" else "pk_gemm"
+    if k == "dw_pk_kernel":
+        return "pk_dw_gate" if args[0] == "true" else "pk_dw"
+    if k == "gram_pk_kernel":
+        return "pk_gram"
+    if k in ("pk_pack_kernel", "pk_unpack_kernel"):
+        return k.replace("_kernel", "")
     if k == "pwdw_kernel":
         return "pwdw_gate" if args[2] == "true" else "pwdw"
     if k == "pwdw_ws_kernel":
@@ -43,10 +51,15 @@ def load(path):
 
 
 def passes_of(name):
-    return sum(1 for n in name.values() if "ln_fold" in n) / LN_FOLD_PER_PASS
+    """Workload passes in the profiled command: two LayerNorm folds per block per fp32 pass, one Gram launch
+    per block per bf16 pass."""
+    folds = sum(1 for n in name.values() if "ln_fold" in n)
+    if folds:
+        return folds / LN_FOLD_PER_PASS
+    return sum(1 for n in name.values() if "gram_pk_kernel" in n) / (LN_FOLD_PER_PASS / 2)
 
 
-def traffic(fetch_csv, write_csv, out):
+def traffic(fetch_csv, write_csv, out, workload="bench.py default (Restormer dim=48 fp32 inference, 16x3x256x256)"):
     f, fn = load(fetch_csv)
     w, wn = load(write_csv)
     passes = passes_of(fn)
@@ -62,7 +75,7 @@ def traffic(fetch_csv, write_csv, out):
         fb, wb = 2 * fe / passes * 1024, wr / passes * 1024
         kernels[g] = {"launches_per_step": lp, "fetch_bytes_per_step": round(fb), "write_bytes_per_step": round(wb),
                       "bytes_per_launch": round((fb + wb) / lp)}
-    json.dump({"workload": "bench.py default (Restormer dim=48 fp32 inference, 16x3x256x256)",
+    json.dump({"workload": workload,
                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of bench.py --steps 1 --warmup 1; "
                          "FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B); KB -> bytes x1024; "
                          f"{passes:g} passes in the profiled command",
@@ -97,6 +110,6 @@ def mfma(counters_csv, out):
 
 if __name__ == "__main__":
     if sys.argv[1] == "traffic":
-        traffic(sys.argv[2], sys.argv[3], sys.argv[4])
+        traffic(*sys.argv[2:6])
     else:
         mfma(sys.argv[2], sys.argv[3])
