@@ -178,12 +178,23 @@ static int pk_block_fwd(const rst_block_desc* d, const rst_block_params* p, cons
     const int64_t cn = (int64_t)C * N;
 
     // ---- MDTA (model/Restromer.py:128-150) ----
-    {
+    // The fused 1x1 + depthwise kernel is routed where it was measured ahead of the pair of kernels: the qkv
+    // product at 96 channels (398 vs 420 us at 16 x 96 x 256 x 256; the gated form 399 vs 387 us, 48 channels
+    // 302 vs 212 us).  RST_BF16_FUSE=0: never, =2: wherever the kernel supports the shape (tests).
+    static const int fuse_mode = getenv("RST_BF16_FUSE") != nullptr ? atoi(getenv("RST_BF16_FUSE")) : 1;
+    const bool fuse_ok = fuse_mode > 0 && pwdw_pk_supported(C / 8, d->W, d->H);
+    const bool fuse = fuse_ok && (fuse_mode == 2 || gemm_pk_ks(C / 8) == 3);
+    const bool fuse_gate = fuse_ok && fuse_mode == 2;
+    if (fuse) {
+        PwDwPk f{};
+        f.A = b.wqkv.frag; f.X = x; f.x_bs = cn; f.Y = qkv; f.y_bs = 3 * cn;
+        f.ln_s = b.wqkv.s; f.ln_c = b.wqkv.c; f.ln_mode = ln_mode; f.dww = b.dw_qkv;
+        f.K = C; f.Kb = C / 8; f.Mb = 3 * C / 8; f.B = B; f.H = d->H; f.W = d->W; f.gate = 0;
+        RST_TRY(pwdw_pk_launch(f, stream));
+    } else {
         GemmPk g = pk_gemm_args(b.wqkv, x, cn, t, 3 * cn, B, N);
         g.ln_mode = ln_mode; g.ln_s = b.wqkv.s; g.ln_c = b.wqkv.c;
         RST_TRY(gemm_pk_launch(g, stream));
-    }
-    {
         DwPk a{};
         a.x = t; a.x_bs = 3 * cn; a.wp = b.dw_qkv; a.y = qkv; a.y_bs = 3 * cn;
         a.B = B; a.Cb = 3 * C / 8; a.H = d->H; a.W = d->W; a.gate = 0;
@@ -218,12 +229,16 @@ static int pk_block_fwd(const rst_block_desc* d, const rst_block_params* p, cons
         RST_TRY(gemm_pk_launch(g, stream));
     }
     // ---- GDFN (model/Restromer.py:99-104) ----
-    {
+    if (fuse_gate) {
+        PwDwPk f{};
+        f.A = b.wpin.frag; f.X = y; f.x_bs = cn; f.Y = gbuf; f.y_bs = (int64_t)Hp * N;
+        f.ln_s = b.wpin.s; f.ln_c = b.wpin.c; f.ln_mode = ln_mode; f.dww = b.dw_ffn;
+        f.K = C; f.Kb = C / 8; f.Mb = 2 * Hp / 8; f.B = B; f.H = d->H; f.W = d->W; f.gate = 1;
+        RST_TRY(pwdw_pk_launch(f, stream));
+    } else {
         GemmPk g = pk_gemm_args(b.wpin, y, cn, u, (int64_t)2 * Hp * N, B, N);
         g.ln_mode = ln_mode; g.ln_s = b.wpin.s; g.ln_c = b.wpin.c;
         RST_TRY(gemm_pk_launch(g, stream));
-    }
-    {
         DwPk a{};
         a.x = u; a.x_bs = (int64_t)2 * Hp * N; a.wp = b.dw_ffn; a.y = gbuf; a.y_bs = (int64_t)Hp * N;
         a.B = B; a.Cb = 2 * Hp / 8; a.H = d->H; a.W = d->W; a.gate = 1;

@@ -481,6 +481,201 @@ int dw_pk_launch(DwPk a, hipStream_t stream) {
     return RST_OK;
 }
 
+// ---- fused 1x1 convolution (folded LayerNorm) -> depthwise 3x3 (-> GELU gate) -----------------------------
+// The 1x1 result never goes to memory, and not to LDS either.  A wave takes a patch of 16 columns x 8 rows of
+// pixels: tile nt of the matrix product is row nt of the patch, so a lane (n, g) ends up holding, for one pair of
+// row tiles, 8 channels of column n in ALL 8 rows -- the vertical taps of the depthwise convolution are other
+// registers of the same lane, the horizontal ones the neighbouring lanes of its group of 16 (DPP row shifts).
+// The inner 14 x (NT-2) pixels of the patch are complete and are stored; patches overlap by the halo (1.5-1.7 x the
+// matrix work and pixel-operand reads, which are the small side of this operation; NT = 8 rows, 6 at K = 96 where
+// the patch's operand would not leave room for two waves per SIMD).  Pixels outside the image are
+// zeroed after the LayerNorm epilogue (the depthwise convolution pads its INPUT with zeros).  The pixel operand
+// of the patch stays in registers for all row-tile pairs; the halves of a pair (4 channels each) are multiplied and
+// convolved one after the other to bound the registers.  Weight fragments and epilogue constants sit in LDS as in
+// gemm_pk_kernel; the depthwise taps come from memory per pair (a few KB, cache resident).
+// grid = (patch groups, row splits, samples); only K <= 96 (KS <= 3).
+template <int KS, int NT, bool GATE>
+__global__ void __launch_bounds__(256, 2)
+pwdw_pk_kernel(const PwDwPk g) {
+    constexpr int RO = NT - 2;                            // complete (stored) rows of a patch
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int pb = g.pb;
+    bf16x8* As = reinterpret_cast<bf16x8*>(smem);
+    float* sc = reinterpret_cast<float*>(smem + (size_t)pb * 2 * KS * 1024);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_ = lane & 15, gq = lane >> 4;
+    const int msplit = blockIdx.y, b = blockIdx.z;
+    {
+        const u32x4* src = reinterpret_cast<const u32x4*>(g.A) + (int64_t)msplit * pb * 2 * KS * 64;
+        u32x4* dst = reinterpret_cast<u32x4*>(smem);
+        for (int i = tid; i < pb * 2 * KS * 64; i += 256) dst[i] = src[i];
+        for (int i = tid; i < pb * 32; i += 256) {
+            sc[i] = g.ln_s[msplit * pb * 32 + i];
+            sc[pb * 32 + i] = g.ln_c[msplit * pb * 32 + i];
+        }
+    }
+    __syncthreads();
+    const int H = g.H, W = g.W;
+    const int64_t N = (int64_t)H * W;
+    const bf16x8* Xp = reinterpret_cast<const bf16x8*>(g.X + (int64_t)b * g.x_bs);
+    bf16_t* Yb = g.Y + (int64_t)b * g.y_bs;
+    const float invK = 1.0f / (float)g.K;
+    const int Kb = g.Kb, Mb = g.Mb;
+    const int pxn = (W + 13) / 14, pyn = (H + RO - 1) / RO;
+    const int npatch = pxn * pyn;
+    const int first = blockIdx.x * g.patches_per_block;
+    const int last = first + g.patches_per_block < npatch ? first + g.patches_per_block : npatch;
+
+    for (int patch = first + wave; patch < last; patch += 4) {
+        const int ty = patch / pxn, tx = patch % pxn;
+        const int x = tx * 14 - 1 + n_, y0 = ty * RO - 1;
+        const int xc = x < 0 ? 0 : (x < W ? x : W - 1);
+        const bool x_in = x >= 0 && x < W;
+        bf16x8 xf[KS][NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int y = y0 + nt;
+            const int yc = y < 0 ? 0 : (y < H ? y : H - 1);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int cb = 4 * ks + gq;
+                const bf16x8 v = Xp[(int64_t)(cb < Kb ? cb : 0) * N + (int64_t)yc * W + xc];
+                const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                xf[ks][nt] = cb < Kb ? v : z;
+            }
+        }
+        float mean[NT], rstd[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                float v[8];
+                unpack8(__builtin_bit_cast(u32x4, xf[ks][nt]), v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s1 += v[j]; s2 = fmaf(v[j], v[j], s2); }
+            }
+            s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+            const float m = s1 * invK;
+            const float var = fmaxf(s2 * invK - m * m, 0.f);
+            mean[nt] = g.ln_mode == 1 ? m : 0.f;
+            rstd[nt] = 1.0f / sqrtf(var + 1e-5f);
+        }
+        for (int p = 0; p < pb; ++p) {
+            const int cb = (msplit * pb + p) * 4 + gq;
+            const int cbc = cb < Mb ? cb : 0;
+            const bf16x8* Ap = As + (size_t)p * 2 * KS * 64 + lane;
+            float o0[RO][4];                                   // the first half's results wait for the second
+#pragma unroll 1
+            for (int h = 0; h < 2; ++h) {
+                f32x4 acc[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 a = Ap[(h * KS + ks) * 64];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, xf[ks][nt], acc[nt], 0, 0, 0);
+                }
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(sc + p * 32 + gq * 8 + 4 * h);
+                const f32x4 c4 = *reinterpret_cast<const f32x4*>(sc + pb * 32 + p * 32 + gq * 8 + 4 * h);
+                // taps of this lane's 4 channels: [tap][4], then the bias
+                f32x4 wt[9];
+                const float* wsrc = g.dww + cbc * 80 + 4 * h;
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) wt[tp] = *reinterpret_cast<const f32x4*>(wsrc + tp * 8);
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(wsrc + 72);
+                float o[RO][4];
+#pragma unroll
+                for (int r = 0; r < RO; ++r)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[r][i] = bias[i];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int y = y0 + nt;
+                    const bool in = x_in && y >= 0 && y < H;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float m = fmaf(fmaf(-mean[nt], s4[i], acc[nt][i]), rstd[nt], c4[i]);
+                        m = in ? m : 0.f;
+                        const float l = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x111, 0xf, 0xf, true));
+                        const float rr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), 0x101, 0xf, 0xf, true));
+                        // patch row nt is window row dy of output row nt + 1 - dy (stored rows: 1..6)
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy) {
+                            const int orow = nt + 1 - dy;
+                            if (orow >= 1 && orow <= RO)
+                                o[orow - 1][i] = fmaf(wt[dy * 3][i], l, fmaf(wt[dy * 3 + 1][i], m, fmaf(wt[dy * 3 + 2][i], rr, o[orow - 1][i])));
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);        // one patch row at a time: keeps the live values few
+                }
+                if (h == 0) {
+#pragma unroll
+                    for (int r = 0; r < RO; ++r)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o0[r][i] = o[r][i];
+                } else {
+                    const bool col_ok = n_ >= 1 && n_ <= 14 && x < W && cb < Mb;
+#pragma unroll
+                    for (int r = 0; r < RO; ++r) {
+                        const int y = y0 + 1 + r;
+                        if (!(col_ok && y < H)) continue;
+                        const int64_t px = (int64_t)y * W + x;
+                        if (GATE) {
+                            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                            u32x2 w2;
+                            w2[0] = pack_bf16(pk_gelu(o0[r][0]) * o[r][0], pk_gelu(o0[r][1]) * o[r][1]);
+                            w2[1] = pack_bf16(pk_gelu(o0[r][2]) * o[r][2], pk_gelu(o0[r][3]) * o[r][3]);
+                            reinterpret_cast<u32x2*>(Yb)[((int64_t)(cb >> 1) * N + px) * 2 + (cb & 1)] = w2;
+                        } else {
+                            u32x4 w4;
+                            w4[0] = pack_bf16(o0[r][0], o0[r][1]); w4[1] = pack_bf16(o0[r][2], o0[r][3]);
+                            w4[2] = pack_bf16(o[r][0], o[r][1]);   w4[3] = pack_bf16(o[r][2], o[r][3]);
+                            reinterpret_cast<u32x4*>(Yb)[(int64_t)cb * N + px] = w4;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+bool pwdw_pk_supported(int Kb, int W, int H) { return gemm_pk_ks(Kb) > 0 && gemm_pk_ks(Kb) <= 3 && W >= 16 && H >= 6; }
+
+int pwdw_pk_launch(PwDwPk g, hipStream_t stream) {
+    const int KS = gemm_pk_ks(g.Kb);
+    RST_REQUIRE(KS > 0 && KS <= 3, "bf16 fused 1x1 + depthwise: %d input channels not supported (at most 96)", g.Kb * 8);
+    RST_REQUIRE(g.A && g.X && g.Y && g.ln_s && g.ln_c && g.dww, "bf16 fused 1x1 + depthwise: null operand");
+    RST_REQUIRE(aligned16(g.A) && aligned16(g.X) && aligned16(g.Y) && aligned16(g.dww), "bf16 fused 1x1 + depthwise: operands must be 16-byte aligned");
+    RST_REQUIRE(g.B <= 65535, "bf16 fused 1x1 + depthwise: batch %d exceeds 65535", g.B);
+    g.pb = gemm_pk_pairs(g.Kb, g.Mb);
+    g.ngroups = (int)cdiv(cdiv(g.Mb, 4), g.pb);
+    const int RO = KS <= 2 ? 6 : 4;
+    const int npatch = (int)(cdiv(g.W, 14) * cdiv(g.H, RO));
+    // about three blocks per CU over the chip, at least one patch per wave
+    int ppb = (int)cdiv((int64_t)npatch * g.B * g.ngroups, 768);
+    ppb = (int)round_up(ppb < 4 ? 4 : ppb, 4);
+    g.patches_per_block = ppb;
+    const dim3 grid((unsigned)cdiv(npatch, ppb), (unsigned)g.ngroups, (unsigned)g.B);
+    const size_t lds = (size_t)g.pb * 2 * KS * 1024 + (size_t)g.pb * 32 * 2 * sizeof(float);
+    RST_REQUIRE(lds <= 64 * 1024, "bf16 fused 1x1 + depthwise: LDS plan of %zu bytes", lds);
+    const double px = (double)g.H * g.W * g.B;
+    const double mout = g.gate ? g.Mb * 4 : g.Mb * 8;
+    ProfScope prof(stream, g.gate ? "pk_pwdw_gate" : "pk_pwdw", px * g.Mb * 8 * (2.0 * g.Kb * 8 + 18.0), px * 2.0 * (g.Kb * 8 + mout));
+#define PWDW_GO(ks)                                                                                              \
+    do {                                                                                                         \
+        if (g.gate) hipLaunchKernelGGL((pwdw_pk_kernel<ks, (ks <= 2 ? 8 : 6), true>), grid, dim3(256), lds, stream, g);   \
+        else hipLaunchKernelGGL((pwdw_pk_kernel<ks, (ks <= 2 ? 8 : 6), false>), grid, dim3(256), lds, stream, g);        \
+    } while (0)
+    if (KS == 1) PWDW_GO(1); else if (KS == 2) PWDW_GO(2); else PWDW_GO(3);
+#undef PWDW_GO
+    RST_LAUNCH_CHECK();
+    return RST_OK;
+}
+
 // ---- Gram matrices q k^T and squared norms over the pixels --------------------------------------------
 // A wave takes a T x T block of 16 x 16 tiles of one (sample, head) over one range of pixels, 32 at a time:
 // the 16-byte chunks of q and k go to a wave-private LDS image as they are, and come back transposed

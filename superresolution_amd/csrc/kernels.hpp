@@ -171,6 +171,18 @@ struct DwPk {
     int rows;                            // filled by the launcher
 };
 int dw_pk_launch(DwPk a, hipStream_t stream);
+// fused 1x1 (folded LayerNorm, ln_mode 1 or 2) -> depthwise 3x3 (-> gate, layout as DwPk): Y = dw(A X) with the
+// intermediate kept in registers.  A, ln_s, ln_c as for GemmPk (shared weights), dww as DwPk::wp.
+struct PwDwPk {
+    const bf16_t* A; const bf16_t* X; int64_t x_bs; bf16_t* Y; int64_t y_bs;
+    const float* ln_s; const float* ln_c; int ln_mode;
+    const float* dww;
+    int K, Kb, Mb;                       // Mb: channel blocks of the intermediate
+    int B, H, W; int gate;
+    int pb, ngroups, patches_per_block;  // filled by the launcher
+};
+bool pwdw_pk_supported(int Kb, int W, int H);
+int pwdw_pk_launch(PwDwPk g, hipStream_t stream);
 // Gram matrices q k^T and squared row norms over the pixels: `splits` slabs per (sample, head)
 struct GramPk {
     const bf16_t* Q; const bf16_t* Kx; int64_t bs;    // first channel block of q / k; elements between samples

@@ -170,3 +170,20 @@ def test_prepared_weights_cache_follows_parameter_updates():
     changed = run(cache)
     assert not torch.equal(changed.view(torch.int16), first.view(torch.int16))
     assert torch.equal(changed.view(torch.int16), run(None).view(torch.int16))
+
+
+@pytest.mark.parametrize("mode", ["0", "2"])
+def test_block_with_fused_kernel_forced_on_and_off(mode):
+    """The fused 1x1 + depthwise kernel (intermediate in registers) is routed only where it was measured
+    faster.  RST_BF16_FUSE=2 forces it wherever it supports the shape (48 and 96 channels, plain and gated),
+    =0 switches it off; the switch is read once per process, so the golden block cases re-run in a child."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, RST_BF16_FUSE=mode)
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_bf16.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "test_block_vs_golden or test_block_vs_oracle_large_mean", "-p", "no:cacheprovider"],
+                       env=env, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
