@@ -177,12 +177,12 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--size", type=int, default=None)
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
-                    help="bf16: activations stored in bf16 between kernels, fp32 sums (infer and frame modes)")
+                    help="bf16: activations stored in bf16 between kernels, fp32 sums (infer, frame and tiled modes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    if args.dtype == "bf16" and args.mode not in ("infer", "frame"):
-        raise SystemExit("--dtype bf16 is available for --mode infer and --mode frame")
+    if args.dtype == "bf16" and args.mode not in ("infer", "frame", "tiled"):
+        raise SystemExit("--dtype bf16 is available for --mode infer, --mode frame and --mode tiled")
     rank, world, local = dist_setup(args.gpus)
     dev = torch.device("cuda", local)
     net = build_model(0).to(dev)
@@ -222,7 +222,7 @@ def main():
                 return net(x)
         scaling = "weak" if args.mode == "frame" else "strong"
         pixels = Hh * Ww * (world if args.mode == "frame" else 1)
-        workload = (f"Restormer(3,3,dim=48) fp32 tiled inference of one 1x3x{Hh}x{Ww} image, 256-px tiles + 32-px overlap, tiles sharded over the GPUs"
+        workload = (f"Restormer(3,3,dim=48) {prec} tiled inference of one 1x3x{Hh}x{Ww} image, 256-px tiles + 32-px overlap, tiles sharded over the GPUs"
                     if args.mode == "tiled" else
                     f"Restormer(3,3,dim=48) fp32 exact inference of one 1x3x{Hh}x{Ww} frame, rows sharded over the GPUs, output gathered on rank 0"
                     if args.mode == "frame_sharded" else f"Restormer(3,3,dim=48) {prec} untiled inference, one 1x3x{Hh}x{Ww} frame per GPU")

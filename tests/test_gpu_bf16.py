@@ -187,3 +187,20 @@ def test_block_with_fused_kernel_forced_on_and_off(mode):
                        env=env, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
+
+
+def test_tiled_inference_bf16_close_to_fp32():
+    """Tile-sharded inference takes the bf16 path tile by tile when the image is bf16: same tiling, outputs within
+    the bf16 tolerance of the fp32 tiles and the same PSNR against a target to 0.01 dB."""
+    import bench
+    from superresolution_amd.parallel import tiled_inference
+    net = bench.build_model(0).cuda().eval()
+    g = torch.Generator().manual_seed(9)
+    img = torch.rand(1, 3, 96, 128, generator=g).cuda()
+    with torch.no_grad():
+        ref = tiled_inference(net, img, tile=64, overlap=16, tile_batch=2)
+        out = tiled_inference(net, img.bfloat16(), tile=64, overlap=16, tile_batch=2)
+    assert out.dtype == torch.bfloat16 and out.shape == ref.shape
+    assert _maxrel(out.float(), ref) < BF16_TOL
+    target = (ref + 0.03 * torch.randn(ref.shape, generator=g).cuda()).clamp(0, 1)
+    assert abs(_psnr(out.float(), target) - _psnr(ref, target)) < 0.01
