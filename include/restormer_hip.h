@@ -263,6 +263,17 @@ int rst_bf16_pack(const void* x, int32_t x_is_fp32, void* y_packed,
                   int32_t B, int32_t C, int64_t N, void* stream);
 int rst_bf16_unpack(const void* x_packed, void* y, int32_t y_is_fp32,
                     int32_t B, int32_t C, int64_t N, void* stream);
+/* Packed <-> channels-last bf16 [B][H][W][C] (the layout the dense 3x3           */
+/* convolutions of Downsample / Upsample / OverlapPatchEmbed, model/Restromer.py  */
+/* :172-215, are handed to MIOpen in).  rst_bf16_from_channels_last applies, on    */
+/* the way, shuffle_mode 0: nothing; 1: nn.PixelUnshuffle(2), model/Restromer.py   */
+/* :196 (x is B x H x W x C, y packed 4C channels at H/2 x W/2); 2:                */
+/* nn.PixelShuffle(2), :211 (y packed C/4 channels at 2H x 2W).  C % 8 == 0        */
+/* (mode 1: C even and the result's 4C a multiple of 8; mode 2: C % 32 == 0).      */
+int rst_bf16_to_channels_last(const void* x_packed, void* y_nhwc,
+                              int32_t B, int32_t C, int64_t N, void* stream);
+int rst_bf16_from_channels_last(const void* x_nhwc, void* y_packed, int32_t shuffle_mode,
+                                int32_t B, int32_t C, int32_t H, int32_t W, void* stream);
 /* nn.Conv2d(Cin, Cout, kernel_size=1) on packed tensors (+ packed residual),     */
 /* model/Restromer.py:309-311,326-328.  Cin <= 480.  y may alias residual.        */
 size_t rst_bf16_conv1x1_workspace_bytes(int32_t Cin, int32_t Cout);

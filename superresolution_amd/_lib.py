@@ -79,6 +79,8 @@ SIGNATURES = {
     "rst_bf16_packed_bytes": (c_size_t, [c_int32, c_int32, c_int64]),
     "rst_bf16_pack": (c_int32, [_P, c_int32, _P, c_int32, c_int32, c_int64, _P]),
     "rst_bf16_unpack": (c_int32, [_P, _P, c_int32, c_int32, c_int32, c_int64, _P]),
+    "rst_bf16_to_channels_last": (c_int32, [_P, _P, c_int32, c_int32, c_int64, _P]),
+    "rst_bf16_from_channels_last": (c_int32, [_P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     "rst_bf16_conv1x1_workspace_bytes": (c_size_t, [c_int32, c_int32]),
     "rst_bf16_conv1x1_fwd": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int64, _P, c_size_t, _P]),
     "rst_bf16_block_workspace_bytes": (c_size_t, [_DESC]),

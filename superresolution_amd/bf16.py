@@ -68,6 +68,39 @@ def unpack(p: Packed, dtype=torch.bfloat16) -> torch.Tensor:
     return out
 
 
+def to_channels_last(p: Packed) -> torch.Tensor:
+    """packed -> a (B, C, H, W) bf16 tensor in torch's channels_last memory format (what the dense 3x3
+    convolutions are run on)."""
+    lib = _lib.load()
+    B, C, H, W = p.shape
+    out = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=p.data.device)
+    check(lib.rst_bf16_to_channels_last(_ptr(p.data), _ptr(out), B, C, H * W, _stream()), "rst_bf16_to_channels_last")
+    return out.permute(0, 3, 1, 2)
+
+
+def from_channels_last(x: torch.Tensor, shuffle: int = 0) -> Packed:
+    """(B, C, H, W) bf16 in channels_last memory format -> packed; shuffle 1: through nn.PixelUnshuffle(2),
+    2: through nn.PixelShuffle(2) (reference: model/Restromer.py:196,211)."""
+    lib = _lib.load()
+    if not x.is_cuda or x.dtype != torch.bfloat16 or x.dim() != 4:
+        raise RuntimeError("from_channels_last: expected a 4-D bf16 tensor on a ROCm GPU")
+    x = x.contiguous(memory_format=torch.channels_last)
+    B, C, H, W = x.shape
+    if shuffle == 0:
+        Co, Ho, Wo = C, H, W
+    elif shuffle == 1:
+        Co, Ho, Wo = C * 4, H // 2, W // 2
+    elif shuffle == 2:
+        Co, Ho, Wo = C // 4, H * 2, W * 2
+    else:
+        raise RuntimeError(f"from_channels_last: shuffle mode {shuffle}")
+    if Co % 8:
+        raise RuntimeError(f"from_channels_last: {Co} result channels (a multiple of 8 is needed)")
+    out = torch.empty((B, Co // 8, Ho, Wo, 8), dtype=torch.bfloat16, device=x.device)
+    check(lib.rst_bf16_from_channels_last(_ptr(x), _ptr(out), int(shuffle), B, C, H, W, _stream()), "rst_bf16_from_channels_last")
+    return Packed(out, Co)
+
+
 def conv1x1(p: Packed, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[Packed] = None) -> Packed:
     """nn.Conv2d(kernel_size=1) on a packed tensor (reference: model/Restromer.py:309-311,326-328)."""
     lib = _lib.load()

@@ -270,6 +270,15 @@ int rst_bf16_unpack(const void* x_packed, void* y, int32_t y_is_fp32, int32_t B,
     return pk_unpack_launch(static_cast<const bf16_t*>(x_packed), y, y_is_fp32, B, C, N, static_cast<hipStream_t>(stream));
 }
 
+int rst_bf16_to_channels_last(const void* x_packed, void* y_nhwc, int32_t B, int32_t C, int64_t N, void* stream) {
+    return pk_to_nhwc_launch(static_cast<const bf16_t*>(x_packed), static_cast<bf16_t*>(y_nhwc), B, C, N, static_cast<hipStream_t>(stream));
+}
+int rst_bf16_from_channels_last(const void* x_nhwc, void* y_packed, int32_t shuffle_mode, int32_t B, int32_t C, int32_t H, int32_t W,
+                                void* stream) {
+    return pk_from_nhwc_launch(static_cast<const bf16_t*>(x_nhwc), static_cast<bf16_t*>(y_packed), shuffle_mode, B, C, H, W,
+                               static_cast<hipStream_t>(stream));
+}
+
 size_t rst_bf16_conv1x1_workspace_bytes(int32_t Cin, int32_t Cout) {
     if (Cin <= 0 || Cout <= 0 || gemm_pk_ks((int)cdiv(Cin, 8)) < 0) return 0;
     PkWeight w = pk_plain_weight(Cout, Cin);

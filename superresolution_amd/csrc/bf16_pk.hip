@@ -866,6 +866,106 @@ pk_unpack_kernel(const bf16_t* __restrict__ src, DST* __restrict__ dst, int C, i
     }
 }
 
+// ---- channels-last neighbours: the dense 3x3 convolutions run in a library that prefers [B][H][W][C] --------------
+// packed -> channels-last bf16: one thread = one 16-byte chunk (C a multiple of 8)
+__global__ void __launch_bounds__(256)
+pk_to_nhwc_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int Cb, int64_t N) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;          // (pixel, channel block), channel block fastest
+    const int b = blockIdx.y;
+    if (e >= N * Cb) return;
+    const int cb = (int)(e % Cb);
+    const int64_t n = e / Cb;
+    reinterpret_cast<u32x4*>(dst)[(int64_t)b * N * Cb + e] = reinterpret_cast<const u32x4*>(src)[((int64_t)b * Cb + cb) * N + n];
+}
+// channels-last bf16 [B][H][W][C] -> packed, optionally through PixelUnshuffle(2) / PixelShuffle(2)
+// (model/Restromer.py:196,211):
+//   mode 0: y[c] = x[c]
+//   mode 1: y[4c + 2i + j][yo][xo] = x[c][2yo + i][2xo + j]          (C -> 4C, H/2 x W/2)
+//   mode 2: y[c][2y + i][2x + j]   = x[4c + 2i + j][y][x]            (C -> C/4, 2H x 2W)
+// one thread = one output chunk (modes 0, 1) or the four output chunks of one input pixel (mode 2)
+template <int MODE>
+__global__ void __launch_bounds__(256)
+pk_from_nhwc_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int C, int H, int W) {
+    const int b = blockIdx.z, ob = blockIdx.y;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bf16_t* S = src + (int64_t)b * H * W * C;
+    if (MODE == 0) {
+        const int64_t N = (int64_t)H * W;
+        if (t >= N) return;
+        reinterpret_cast<u32x4*>(dst)[((int64_t)b * (C / 8) + ob) * N + t] = *reinterpret_cast<const u32x4*>(S + t * C + ob * 8);
+    } else if (MODE == 1) {
+        const int Ho = H / 2, Wo = W / 2;
+        const int64_t No = (int64_t)Ho * Wo;
+        if (t >= No) return;
+        const int yo = (int)(t / Wo), xo = (int)(t % Wo);
+        uint32_t w[4];                                     // (c0, c1) at (i, j) = (0,0) (0,1) (1,0) (1,1)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            w[q] = *reinterpret_cast<const uint32_t*>(S + ((int64_t)(2 * yo + (q >> 1)) * W + 2 * xo + (q & 1)) * C + ob * 2);
+        u32x4 o;
+        o[0] = (w[0] & 0xffffu) | (w[1] << 16);
+        o[1] = (w[2] & 0xffffu) | (w[3] << 16);
+        o[2] = (w[0] >> 16) | (w[1] & 0xffff0000u);
+        o[3] = (w[2] >> 16) | (w[3] & 0xffff0000u);
+        reinterpret_cast<u32x4*>(dst)[((int64_t)b * (C / 2) + ob) * No + t] = o;
+    } else {
+        const int64_t N = (int64_t)H * W;
+        if (t >= N) return;
+        const int y = (int)(t / W), x = (int)(t % W);
+        const u32x4* in = reinterpret_cast<const u32x4*>(S + t * C + ob * 32);
+        uint32_t e[16];                                    // 32 channels: element 4q + 2i + j, two per word
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const u32x4 v = in[k];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) e[4 * k + m] = v[m];
+        }
+        const int64_t No = 4 * N;
+        u32x4* out = reinterpret_cast<u32x4*>(dst) + ((int64_t)b * (C / 32) + ob) * No;
+#pragma unroll
+        for (int ij = 0; ij < 4; ++ij) {
+            // channel q of the chunk is element 4q + ij: word 2q + (ij >> 1), half ij & 1
+            u32x4 o;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const uint32_t a = e[2 * (2 * m) + (ij >> 1)], c = e[2 * (2 * m + 1) + (ij >> 1)];
+                o[m] = (ij & 1) ? ((a >> 16) | (c & 0xffff0000u)) : ((a & 0xffffu) | (c << 16));
+            }
+            out[(int64_t)(2 * y + (ij >> 1)) * (2 * W) + 2 * x + (ij & 1)] = o;
+        }
+    }
+}
+
+int pk_to_nhwc_launch(const bf16_t* src, bf16_t* dst, int B, int C, int64_t N, hipStream_t stream) {
+    RST_REQUIRE(src && dst && B > 0 && C > 0 && N > 0, "bf16 channels-last: empty shape");
+    RST_REQUIRE(C % 8 == 0, "bf16 channels-last: %d channels (a multiple of 8 is needed)", C);
+    RST_REQUIRE(aligned16(src) && aligned16(dst), "bf16 channels-last: operands must be 16-byte aligned");
+    RST_REQUIRE(B <= 65535, "bf16 channels-last: batch %d exceeds 65535", B);
+    ProfScope prof(stream, "pk_to_nhwc", 0.0, (double)B * C * N * 4.0);
+    hipLaunchKernelGGL(pk_to_nhwc_kernel, dim3((unsigned)cdiv(N * (C / 8), 256), B), dim3(256), 0, stream, src, dst, C / 8, N);
+    RST_LAUNCH_CHECK();
+    return RST_OK;
+}
+int pk_from_nhwc_launch(const bf16_t* src, bf16_t* dst, int mode, int B, int C, int H, int W, hipStream_t stream) {
+    RST_REQUIRE(src && dst && B > 0 && C > 0 && H > 0 && W > 0, "bf16 channels-last: empty shape");
+    RST_REQUIRE(mode >= 0 && mode <= 2, "bf16 channels-last: mode %d", mode);
+    RST_REQUIRE(aligned16(src) && aligned16(dst), "bf16 channels-last: operands must be 16-byte aligned");
+    RST_REQUIRE(B <= 65535, "bf16 channels-last: batch %d exceeds 65535", B);
+    ProfScope prof(stream, mode == 0 ? "pk_from_nhwc" : (mode == 1 ? "pk_unshuffle" : "pk_shuffle"), 0.0, (double)B * C * H * W * 4.0);
+    if (mode == 0) {
+        RST_REQUIRE(C % 8 == 0, "bf16 channels-last: %d channels (a multiple of 8 is needed)", C);
+        hipLaunchKernelGGL(pk_from_nhwc_kernel<0>, dim3((unsigned)cdiv((int64_t)H * W, 256), C / 8, B), dim3(256), 0, stream, src, dst, C, H, W);
+    } else if (mode == 1) {
+        RST_REQUIRE(C % 2 == 0 && H % 2 == 0 && W % 2 == 0, "bf16 pixel-unshuffle: C=%d H=%d W=%d must be even", C, H, W);
+        hipLaunchKernelGGL(pk_from_nhwc_kernel<1>, dim3((unsigned)cdiv((int64_t)(H / 2) * (W / 2), 256), C / 2, B), dim3(256), 0, stream, src, dst, C, H, W);
+    } else {
+        RST_REQUIRE(C % 32 == 0, "bf16 pixel-shuffle: %d channels (a multiple of 32 is needed)", C);
+        hipLaunchKernelGGL(pk_from_nhwc_kernel<2>, dim3((unsigned)cdiv((int64_t)H * W, 256), C / 32, B), dim3(256), 0, stream, src, dst, C, H, W);
+    }
+    RST_LAUNCH_CHECK();
+    return RST_OK;
+}
+
 int pk_pack_launch(const void* src, int src_is_fp32, bf16_t* dst, int B, int C, int64_t N, hipStream_t stream) {
     RST_REQUIRE(src && dst && B > 0 && C > 0 && N > 0 && N % 2 == 0, "bf16 pack: bad shape B=%d C=%d N=%lld (N must be even)", B, C, (long long)N);
     RST_REQUIRE(aligned16(dst) && (reinterpret_cast<uintptr_t>(src) & 3u) == 0, "bf16 pack: misaligned operand");

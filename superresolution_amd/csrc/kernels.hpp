@@ -197,5 +197,8 @@ void gram_pk_plan(int c, int64_t N, int BH, int* splits, int64_t* chunk);
 int gram_pk_launch(GramPk g, hipStream_t stream);
 int pk_pack_launch(const void* src, int src_is_fp32, bf16_t* dst, int B, int C, int64_t N, hipStream_t stream);
 int pk_unpack_launch(const bf16_t* src, void* dst, int dst_is_fp32, int B, int C, int64_t N, hipStream_t stream);
+// packed <-> channels-last bf16 [B][H][W][C]; mode 1 / 2: through PixelUnshuffle(2) / PixelShuffle(2)
+int pk_to_nhwc_launch(const bf16_t* src, bf16_t* dst, int B, int C, int64_t N, hipStream_t stream);
+int pk_from_nhwc_launch(const bf16_t* src, bf16_t* dst, int mode, int B, int C, int H, int W, hipStream_t stream);
 
 }  // namespace rst

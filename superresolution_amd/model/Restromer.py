@@ -234,15 +234,20 @@ class Restormer(nn.Module):
     def _forward_bf16(self, inp_img):
         """Inference with bf16 activations (a bf16 input, or an fp32 input under bf16 autocast): every
         TransformerBlock and 1x1 convolution runs on the library's channel-packed bf16 tensors with fp32 sums
-        and fp32 parameters; the dense 3x3 convolutions run in bf16 through torch, the last layer and the
-        bilinear residual in fp32.  The result has the input's dtype."""
+        and fp32 parameters, PixelUnshuffle / PixelShuffle happen inside the library's layout conversions; the dense
+        3x3 convolutions run in bf16 through torch (channels-last), the last layer and the bilinear residual in
+        fp32.  The result has the input's dtype."""
         from .. import bf16 as pk
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise RuntimeError("the bf16 path is inference only: call it under torch.no_grad()")
         bf = torch.bfloat16
 
+        cl = torch.channels_last
+
         def conv3(x, conv):
-            return F.conv2d(x, conv.weight.to(bf), None if conv.bias is None else conv.bias.to(bf), padding=1)
+            # dense 3x3 through torch (MIOpen), channels-last on both sides so that no transposition runs around it
+            return F.conv2d(x, conv.weight.to(bf).contiguous(memory_format=cl), None if conv.bias is None else conv.bias.to(bf),
+                            padding=1)
 
         def stage(p, blocks):
             for blk in blocks:
@@ -251,13 +256,13 @@ class Restormer(nn.Module):
                 pk.block_(p, blk.attn.num_heads, blk.ffn.hidden_features, blk._params(), blk._pk_cache)
             return p
 
-        def down(p, mod):
-            return pk.pack(F.pixel_unshuffle(conv3(pk.unpack(p), mod.body[0]), 2))
+        def down(p, mod):        # conv3x3 then PixelUnshuffle(2), the shuffle inside the layout conversion
+            return pk.from_channels_last(conv3(pk.to_channels_last(p), mod.body[0]), 1)
 
-        def up(p, mod):
-            return pk.pack(F.pixel_shuffle(conv3(pk.unpack(p), mod.body[0]), 2))
+        def up(p, mod):          # conv3x3 then PixelShuffle(2)
+            return pk.from_channels_last(conv3(pk.to_channels_last(p), mod.body[0]), 2)
 
-        e1_in = pk.pack(conv3(inp_img.to(bf), self.patch_embed.proj))
+        e1_in = pk.from_channels_last(conv3(inp_img.to(bf).contiguous(memory_format=cl), self.patch_embed.proj), 0)
         skip = None
         if self.dual_pixel_task:
             skip = pk.unpack(pk.conv1x1(e1_in, self.skip_conv.weight, self.skip_conv.bias))
@@ -270,16 +275,16 @@ class Restormer(nn.Module):
         d2 = pk.conv1x1(pk.cat(up(d3, self.up3_2), e2), self.reduce_chan_level2.weight, self.reduce_chan_level2.bias)
         d2 = stage(d2, self.decoder_level2)
         d1 = stage(stage(pk.cat(up(d2, self.up2_1), e1), self.decoder_level1), self.refinement)
-        upx = F.pixel_shuffle(conv3(pk.unpack(d1), self.output_upscale.body[0]), 2)
+        upx = F.pixel_shuffle(conv3(pk.to_channels_last(d1), self.output_upscale.body[0]), 2)
         if self.dual_pixel_task:
-            out = conv3(upx + skip, self.output).float()
+            out = conv3(upx + skip, self.output).float().contiguous()
         else:
             base = F.interpolate(inp_img.float(), scale_factor=2, mode="bilinear", align_corners=False)
             if self.output.weight.shape[0] <= 4:
                 bias = None if self.output.bias is None else self.output.bias.float()
-                out = ops.conv3x3_fewout(upx.float(), self.output.weight.float(), bias, base)
+                out = ops.conv3x3_fewout(upx.to(dtype=torch.float32, memory_format=torch.contiguous_format), self.output.weight.float(), bias, base)
             else:
-                out = conv3(upx, self.output).float() + base
+                out = conv3(upx, self.output).float().contiguous() + base
         return out.to(inp_img.dtype)
 
     def forward(self, inp_img):

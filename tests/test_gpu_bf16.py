@@ -204,3 +204,40 @@ def test_tiled_inference_bf16_close_to_fp32():
     assert _maxrel(out.float(), ref) < BF16_TOL
     target = (ref + 0.03 * torch.randn(ref.shape, generator=g).cuda()).clamp(0, 1)
     assert abs(_psnr(out.float(), target) - _psnr(ref, target)) < 0.01
+
+
+@pytest.mark.parametrize("shape", [(2, 48, 6, 10), (1, 96, 8, 4), (1, 8, 2, 2)])
+def test_channels_last_round_trip_exact(shape):
+    from superresolution_amd import bf16
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g).bfloat16().cuda()
+    p = bf16.pack(x)
+    cl = bf16.to_channels_last(p)
+    assert cl.shape == x.shape and cl.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(cl.float(), x.float())
+    back = bf16.from_channels_last(cl, 0)
+    assert torch.equal(back.data.view(torch.int16), p.data.view(torch.int16))
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 6, 12), (1, 96, 8, 4), (1, 2, 4, 4)])
+def test_pixel_unshuffle_into_packed_exact(shape):
+    """rst_bf16_from_channels_last mode 1 == nn.PixelUnshuffle(2) (reference model/Restromer.py:196) then pack."""
+    from superresolution_amd import bf16
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    x = torch.randn(*shape, generator=g).bfloat16().cuda()
+    got = bf16.from_channels_last(x.contiguous(memory_format=torch.channels_last), 1)
+    ref = torch.nn.functional.pixel_unshuffle(x, 2)
+    assert got.shape == tuple(ref.shape)
+    assert torch.equal(bf16.unpack(got).float(), ref.float())
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 6, 10), (1, 192, 4, 8), (1, 768, 2, 2)])
+def test_pixel_shuffle_into_packed_exact(shape):
+    """rst_bf16_from_channels_last mode 2 == nn.PixelShuffle(2) (reference model/Restromer.py:211) then pack."""
+    from superresolution_amd import bf16
+    g = torch.Generator().manual_seed(sum(shape) + 2)
+    x = torch.randn(*shape, generator=g).bfloat16().cuda()
+    got = bf16.from_channels_last(x.contiguous(memory_format=torch.channels_last), 2)
+    ref = torch.nn.functional.pixel_shuffle(x, 2)
+    assert got.shape == tuple(ref.shape)
+    assert torch.equal(bf16.unpack(got).float(), ref.float())
