@@ -453,12 +453,122 @@ dw_pk_kernel(const DwPk a, const float* __restrict__ wp) {
     }
 }
 
+// The same convolution on the matrix pipe.  A 16-byte chunk of a neighbouring pixel is already an MFMA B operand
+// (8 consecutive k of pixel n), so the k axis is made of tap slots: a wave takes 16 columns x 2 output rows of one
+// channel block, its 4 input rows x 3 column offsets are 12 slots = 3 k-steps x 4 lane groups, and lane (n, g) of
+// k-step s loads the chunk of slot 4s + g for its column -- three loads, no unpacking, no vector multiply.  The A
+// operand is the tap table as a sparse 16 x 96 matrix built once per wave: rows 0-7 are the 8 channels of the upper
+// output row, rows 8-15 of the lower one, and row m has one non-zero per slot, the tap of its channel (bf16).
+// The result lands 4 rows per lane: (GATE) the rows are ordered x1_0 x2_0 x1_1 x2_1 | ..., so a lane holds both
+// factors of two gated outputs and stores 4 bytes; (plain) 4 channels, 8 bytes.
+// grid = (ceil(W/64) * row ranges, channel blocks, B), one wave per 16-column strip, `rows` rows per range.
+template <bool GATE>
+__global__ void __launch_bounds__(256)
+dwm_pk_kernel(const DwPk a, const float* __restrict__ wp) {
+    const int cb = blockIdx.y, b = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_ = lane & 15, gq = lane >> 4;
+    const float* wl = wp + cb * 80;
+    const int strips64 = (a.W + 63) / 64;
+    const int range = blockIdx.x / strips64;
+    const int xs = (blockIdx.x % strips64) * 64 + wave * 16;        // first column of this wave's strip
+    const int y_begin = range * a.rows;
+    if (xs >= a.W || y_begin >= a.H) return;
+    const int y_end = y_begin + a.rows < a.H ? y_begin + a.rows : a.H;
+    const int64_t N = (int64_t)a.H * a.W;
+    const u32x4* X = reinterpret_cast<const u32x4*>(a.x + (int64_t)b * a.x_bs) + (int64_t)cb * N;
+    char* Yb = reinterpret_cast<char*>(a.y + (int64_t)b * a.y_bs);
+    // position in the channel block of accumulator row q (0..7) of either output row
+    auto pos_of = [](int q) { return GATE ? ((q & 1) ? 4 + (q >> 1) : (q >> 1)) : q; };
+    // A fragments: this lane is matrix row m = n_, k-group gq
+    bf16x8 af[3];
+    {
+        const int m = n_, orow = m >> 3, p = pos_of(m & 7);
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+            const int t = 4 * s3 + gq, i = t / 3, d = t % 3, dy = i - orow;
+            float w = 0.f;
+            if (dy >= 0 && dy <= 2) w = wl[(dy * 3 + d) * 8 + p];
+            const uint32_t bits = to_bf16_bits(w);
+            u32x4 f = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if ((p >> 1) == k) f[k] = (p & 1) ? (bits << 16) : bits;
+            af[s3] = __builtin_bit_cast(bf16x8, f);
+        }
+    }
+    // epilogue constants of this lane's 4 accumulator rows
+    float bias[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias[r] = wl[72 + pos_of((4 * gq + r) & 7)];
+    const int x = xs + n_;
+    const bool x_ok = x < a.W;
+    // slot of this lane at k-step s3: input row offset and column
+    int si[3], sx[3]; bool sxok[3];
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+        const int t = 4 * s3 + gq;
+        si[s3] = t / 3 - 1;
+        const int xx = x + t % 3 - 1;
+        sxok[s3] = xx >= 0 && xx < a.W;
+        sx[s3] = xx < 0 ? 0 : (xx < a.W ? xx : a.W - 1);
+    }
+    auto fetch = [&](u32x4 (&dst)[3], int y) {
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+            const int yy = y + si[s3];
+            dst[s3] = X[(int64_t)(yy < 0 ? 0 : (yy < a.H ? yy : a.H - 1)) * a.W + sx[s3]];
+        }
+    };
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    u32x4 cur[3], nxt[3];
+    fetch(cur, y_begin);
+    for (int y = y_begin; y < y_end; y += 2) {
+        fetch(nxt, y + 2 < y_end ? y + 2 : y);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+            const int yy = y + si[s3];
+            const bool ok = sxok[s3] && yy >= 0 && yy < a.H;
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s3], __builtin_bit_cast(bf16x8, ok ? cur[s3] : zero), acc, 0, 0, 0);
+        }
+        const int yo = y + (gq >> 1);
+        if (x_ok && yo < y_end) {
+            const int64_t px = (int64_t)yo * a.W + x;
+            if (GATE) {
+                const uint32_t o = pack_bf16(pk_gelu(acc[0] + bias[0]) * (acc[1] + bias[1]), pk_gelu(acc[2] + bias[2]) * (acc[3] + bias[3]));
+                *reinterpret_cast<uint32_t*>(Yb + (((int64_t)(cb >> 1) * N + px) * 16 + (cb & 1) * 8 + (gq & 1) * 4)) = o;
+            } else {
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                u32x2 o;
+                o[0] = pack_bf16(acc[0] + bias[0], acc[1] + bias[1]);
+                o[1] = pack_bf16(acc[2] + bias[2], acc[3] + bias[3]);
+                *reinterpret_cast<u32x2*>(Yb + (((int64_t)cb * N + px) * 16 + (gq & 1) * 8)) = o;
+            }
+        }
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) cur[s3] = nxt[s3];
+    }
+}
+
 int dw_pk_launch(DwPk a, hipStream_t stream) {
     RST_REQUIRE(a.x && a.wp && a.y, "bf16 depthwise: null operand");
     RST_REQUIRE(aligned16(a.x) && aligned16(a.y), "bf16 depthwise: operands must be 16-byte aligned");
     RST_REQUIRE(a.W % 2 == 0 && a.W >= 2, "bf16 depthwise: width %d must be even", a.W);
     RST_REQUIRE(a.B <= 65535 && a.Cb <= 65535, "bf16 depthwise: batch or channel count exceeds 65535");
     // rows per strip: long strips re-read fewer halo rows; short ones give the chip enough threads
+    static const int mfma_mode = getenv("RST_DW_MFMA") ? atoi(getenv("RST_DW_MFMA")) : 0;     // bit 0: plain, bit 1: gated
+    if ((a.gate && (mfma_mode & 2)) || (!a.gate && (mfma_mode & 1))) {
+        static const int mrows = getenv("RST_DW_MROWS") ? atoi(getenv("RST_DW_MROWS")) : 32;
+        a.rows = mrows;
+        const dim3 grid((unsigned)(cdiv(a.W, 64) * cdiv(a.H, a.rows)), a.Cb, a.B);
+        const double el = (double)a.B * a.Cb * 8 * a.H * a.W;
+        ProfScope prof(stream, a.gate ? "pk_dw_gate" : "pk_dw", el * 18.0, el * 2.0 * (a.gate ? 1.5 : 2.0));
+        if (a.gate) hipLaunchKernelGGL(dwm_pk_kernel<true>, grid, dim3(256), 0, stream, a, a.wp);
+        else hipLaunchKernelGGL(dwm_pk_kernel<false>, grid, dim3(256), 0, stream, a, a.wp);
+        RST_LAUNCH_CHECK();
+        return RST_OK;
+    }
     // measured on 16 x 96 x 256 x 256: plain 1 pixel per thread / 8-row strips 255 us, 2 pixels / 16 rows 274 us;
     // gated 237 us and 222 us
     const int px = a.gate ? 2 : 1;

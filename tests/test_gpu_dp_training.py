@@ -1,10 +1,13 @@
 """Data-parallel training of the HIP network: two ranks (sharing the one card, gloo) with batch 2 each must walk
 the same trajectory as one process with batch 4 (L1 mean => averaged gradients; clip and Adam after the all-reduce)."""
+import datetime
 import os
 import socket
 import sys
 
 import pytest
+
+from golden_util import spawn_bounded
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -35,7 +38,7 @@ def _worker(rank, world, port, out_path):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     from superresolution_amd.parallel import DataParallelTrainer
     net = _net()
     trainer = DataParallelTrainer(net, bucket_mb=0.05)          # several buckets
@@ -52,7 +55,7 @@ def _worker(rank, world, port, out_path):
 def test_two_ranks_match_one_process(tmp_path):
     from superresolution_amd.parallel import DataParallelTrainer
     out = str(tmp_path / "dp.pt")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    spawn_bounded(_worker, (2, _free_port(), out), 2)
     got = torch.load(out, weights_only=True)
     net = _net()
     trainer = DataParallelTrainer(net, world_size=1)

@@ -1,10 +1,13 @@
 """Exact row-sharded inference of one frame: every rank runs its row slab (+2 halo rows), the attention's sums over
 all pixels are all-reduced inside every block.  The result must equal the network on the whole frame."""
+import datetime
 import os
 import socket
 import sys
 
 import pytest
+
+from golden_util import spawn_bounded
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -61,7 +64,7 @@ def _worker(rank, world, port, name, out_path):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)      # both ranks share the one card: no RCCL here
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))      # both ranks share the one card: no RCCL here
     from superresolution_amd.parallel import sharded_frame_inference
     dim, h, w = CASES[name]
     net, x = _net(dim), _image(h, w)
@@ -80,7 +83,7 @@ def _worker(rank, world, port, name, out_path):
 @pytest.mark.parametrize("name", list(CASES))
 def test_ranks_on_one_card_equal_whole_frame(name, world, tmp_path):
     out_path = str(tmp_path / "r.pt")
-    mp.spawn(_worker, args=(world, _free_port(), name, out_path), nprocs=world, join=True)
+    spawn_bounded(_worker, (world, _free_port(), name, out_path), world)
     r = torch.load(out_path)
     assert r["shape"] == r["ref_shape"]
     assert r["err"] < 2e-6, r

@@ -3,10 +3,13 @@
 The distributed logic (gradient buckets + all-reduce, tile sharding + stitching) is
 independent of the HIP kernels, so it is exercised here with small stand-in
 modules made of stock torch layers."""
+import datetime
 import os
 import socket
 
 import pytest
+
+from golden_util import spawn_bounded
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -38,7 +41,7 @@ class _TinySR(nn.Module):
 def _init(rank, world, port):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     torch.set_num_threads(1)
 
 
@@ -70,7 +73,7 @@ def _dp_worker(rank, world, port, out_path):
 def test_data_parallel_matches_single_process(tmp_path):
     """2 ranks x batch 2 == 1 process x batch 4 (L1 mean => averaged gradients), incl. clip + Adam."""
     out = str(tmp_path / "dp.pt")
-    mp.spawn(_dp_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    spawn_bounded(_dp_worker, (2, _free_port(), out), 2)
     got = torch.load(out, weights_only=True)
     torch.manual_seed(0)
     net = _TinySR()
@@ -119,7 +122,7 @@ def _tile_worker(rank, world, port, out_path):
 
 def test_tile_sharded_inference_two_ranks(tmp_path):
     out = str(tmp_path / "tiles.pt")
-    mp.spawn(_tile_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    spawn_bounded(_tile_worker, (2, _free_port(), out), 2)
     got = torch.load(out, weights_only=True)
     torch.manual_seed(0)
     net = _TinySR().eval()
@@ -180,5 +183,5 @@ def _halo_worker(rank, world, port, out_path):
 @pytest.mark.parametrize("world", [2, 3])
 def test_halo_rows_come_from_the_neighbours(world, tmp_path):
     out = str(tmp_path / "halo.pt")
-    mp.spawn(_halo_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    spawn_bounded(_halo_worker, (world, _free_port(), out), world)
     assert torch.load(out) == [1.0] * world
