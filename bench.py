@@ -107,10 +107,10 @@ def kernel_profile(run_once):
 
 def measured_traffic(name, batch, size, mode, dtype="f32"):
     """HBM bytes per launch of kernel group `name`, from the committed rocprofv3 --pmc run of this
-    same workload (profiles/r1_e_hbm_traffic.json, r1_f_bf16_hbm_traffic.json for --dtype bf16; FETCH_SIZE and
+    same workload (profiles/r1_e_hbm_traffic.json, r1_g_bf16_hbm_traffic.json for --dtype bf16; FETCH_SIZE and
     WRITE_SIZE collected in separate passes, FETCH_SIZE doubled as gfx950 requires).  None for any other
     workload or kernel."""
-    path = os.path.join(ROOT, "profiles", "r1_e_hbm_traffic.json" if dtype == "f32" else "r1_f_bf16_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r1_e_hbm_traffic.json" if dtype == "f32" else "r1_g_bf16_hbm_traffic.json")
     try:
         d = json.load(open(path))
     except (OSError, ValueError):

@@ -172,15 +172,17 @@ def test_prepared_weights_cache_follows_parameter_updates():
     assert torch.equal(changed.view(torch.int16), run(None).view(torch.int16))
 
 
-@pytest.mark.parametrize("mode", ["0", "2"])
-def test_block_with_fused_kernel_forced_on_and_off(mode):
+@pytest.mark.parametrize("switch", [{"RST_BF16_FUSE": "0"}, {"RST_BF16_FUSE": "2"}, {"RST_DW_MFMA": "3", "RST_BF16_FUSE": "0"}],
+                         ids=["unfused", "fused_everywhere", "depthwise_on_matrix_pipe"])
+def test_block_with_kernel_variants_forced(switch):
     """The fused 1x1 + depthwise kernel (intermediate in registers) is routed only where it was measured
     faster.  RST_BF16_FUSE=2 forces it wherever it supports the shape (48 and 96 channels, plain and gated),
-    =0 switches it off; the switch is read once per process, so the golden block cases re-run in a child."""
+    =0 switches it off; RST_DW_MFMA=3 runs both depthwise convolutions on the matrix pipe (dwm_pk_kernel, not
+    routed by default).  The switches are read once per process, so the golden block cases re-run in a child."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, RST_BF16_FUSE=mode)
+    env = dict(os.environ, **switch)
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_bf16.py"), "-q", "-x", "-m", "gpu",
                         "-k", "test_block_vs_golden or test_block_vs_oracle_large_mean", "-p", "no:cacheprovider"],
