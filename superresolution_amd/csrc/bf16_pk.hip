@@ -753,6 +753,205 @@ pwdw_pk_kernel(const PwDwPk g) {
     }
 }
 
+// ---- fused 1x1 (folded LayerNorm) -> depthwise 3x3 (-> gate), both on the matrix pipe ----------------------
+// A block owns a strip of 32 columns (30 stored + the halo column on either side), all channels, and walks down a
+// range of rows.  Phase G: the 1x1 product of a row of the strip, LayerNorm epilogue, zero outside the image, packed
+// to bf16 chunks and written into a ring of 4 rows in LDS -- the chunks are written exactly as the depthwise
+// convolution's B operand wants them.  Phase D (every second row): the depthwise convolution of two output rows
+// as in dwm_pk_kernel, its operand chunks read from the ring with ds_read_b128, the tap matrices of the wave's
+// channel blocks resident in registers.  The intermediate never leaves the CU, nothing is unpacked, and the vector
+// unit only runs the two epilogues.  A wave takes every fourth tile pair in G and every fourth channel block in D.
+// grid = (strips * row ranges, 1, samples)
+template <int KS, int CBW, bool GATE>
+__global__ void __launch_bounds__(256)
+pwdw_ring_kernel(const PwDwPk g) {
+    constexpr int TW = 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int Mb = g.Mb, npairs = (Mb + 3) / 4;
+    bf16x8* As = reinterpret_cast<bf16x8*>(smem);                                    // [npairs*2][KS][64]
+    float* sc = reinterpret_cast<float*>(smem + (size_t)npairs * 2 * KS * 1024);    // [2][npairs*32]
+    char* ring = smem + (size_t)npairs * 2 * KS * 1024 + (size_t)npairs * 32 * 2 * sizeof(float);   // [4][Mb][TW] chunks
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_ = lane & 15, gq = lane >> 4;
+    const int b = blockIdx.z;
+    {
+        const u32x4* src = reinterpret_cast<const u32x4*>(g.A);
+        u32x4* dst = reinterpret_cast<u32x4*>(smem);
+        for (int i = tid; i < npairs * 2 * KS * 64; i += 256) dst[i] = src[i];
+        for (int i = tid; i < npairs * 32; i += 256) { sc[i] = g.ln_s[i]; sc[npairs * 32 + i] = g.ln_c[i]; }
+    }
+    const int H = g.H, W = g.W;
+    const int64_t N = (int64_t)H * W;
+    const int nstrips = (W + 29) / 30;
+    const int strip = blockIdx.x % nstrips, range = blockIdx.x / nstrips;
+    const int x0 = strip * 30 - 1;                                   // image column of strip column 0
+    const int y_begin = range * g.rows;
+    const int y_end = y_begin + g.rows < H ? y_begin + g.rows : H;
+    const bf16x8* Xp = reinterpret_cast<const bf16x8*>(g.X + (int64_t)b * g.x_bs);
+    char* Yb = reinterpret_cast<char*>(g.Y + (int64_t)b * g.y_bs);
+    const float invK = 1.0f / (float)g.K;
+    const int Kb = g.Kb;
+    auto pos_of = [](int q) { return GATE ? ((q & 1) ? 4 + (q >> 1) : (q >> 1)) : q; };
+
+    // tap matrices of this wave's channel blocks (cb = wave + 4 j), as in dwm_pk_kernel, and the biases of the
+    // lane's 4 accumulator rows
+    bf16x8 dwa[CBW][3];
+    float dbias[CBW][4];
+#pragma unroll
+    for (int j = 0; j < CBW; ++j) {
+        const int cb = wave + 4 * j;
+        const float* wl = g.dww + (cb < Mb ? cb : 0) * 80;
+        const int m = n_, orow = m >> 3, p = pos_of(m & 7);
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+            const int t = 4 * s3 + gq, i = t / 3, d = t % 3, dy = i - orow;
+            float w = 0.f;
+            if (dy >= 0 && dy <= 2) w = wl[(dy * 3 + d) * 8 + p];
+            const uint32_t bits = to_bf16_bits(w);
+            u32x4 f = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if ((p >> 1) == k) f[k] = (p & 1) ? (bits << 16) : bits;
+            dwa[j][s3] = __builtin_bit_cast(bf16x8, f);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dbias[j][r] = wl[72 + pos_of((4 * gq + r) & 7)];
+    }
+    // ring offsets of this lane's three operand chunks (k-step s3 -> slot 4 s3 + gq -> row offset, column)
+    int drow[3], dcol[3][2];
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+        const int t = 4 * s3 + gq;
+        drow[s3] = t / 3 - 1;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int c = 16 * nt + n_ + t % 3 - 1;
+            dcol[s3][nt] = c < 0 ? 0 : (c < TW ? c : TW - 1);          // only the unstored halo columns clamp
+        }
+    }
+    __syncthreads();
+
+    // pixel operand of one row of the strip
+    auto xload = [&](bf16x8 (&dst)[KS][2], int ry) {
+        const int yc = ry < 0 ? 0 : (ry < H ? ry : H - 1);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int x = x0 + 16 * nt + n_;
+            const int xc = x < 0 ? 0 : (x < W ? x : W - 1);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int cb = 4 * ks + gq;
+                const bf16x8 v = Xp[(int64_t)(cb < Kb ? cb : 0) * N + (int64_t)yc * W + xc];
+                const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                dst[ks][nt] = cb < Kb ? v : z;
+            }
+        }
+    };
+    // phase G for row ry
+    auto gemm_row = [&](const bf16x8 (&xf)[KS][2], int ry) {
+        float mean[2], rstd[2]; bool in[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                float v[8];
+                unpack8(__builtin_bit_cast(u32x4, xf[ks][nt]), v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { s1 += v[j]; s2 = fmaf(v[j], v[j], s2); }
+            }
+            s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+            const float m = s1 * invK;
+            const float var = fmaxf(s2 * invK - m * m, 0.f);
+            mean[nt] = g.ln_mode == 1 ? m : 0.f;
+            rstd[nt] = 1.0f / sqrtf(var + 1e-5f);
+            const int x = x0 + 16 * nt + n_;
+            in[nt] = ry >= 0 && ry < H && x >= 0 && x < W;
+        }
+        char* rrow = ring + (size_t)(ry & 3) * Mb * (TW * 16);
+        for (int p = wave; p < npairs; p += 4) {
+            f32x4 acc[2][2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[h][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const bf16x8* Ap = As + (size_t)p * 2 * KS * 64 + lane;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 a0 = Ap[ks * 64], a1 = Ap[(KS + ks) * 64];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, xf[ks][nt], acc[0][nt], 0, 0, 0);
+                    acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, xf[ks][nt], acc[1][nt], 0, 0, 0);
+                }
+            }
+            const int cb = p * 4 + gq;
+            if (cb >= Mb) continue;
+            const f32x4* sp = reinterpret_cast<const f32x4*>(sc + p * 32 + gq * 8);
+            const f32x4* cp = reinterpret_cast<const f32x4*>(sc + npairs * 32 + p * 32 + gq * 8);
+            const f32x4 sa = sp[0], sb = sp[1], ca = cp[0], cc = cp[1];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = fmaf(fmaf(-mean[nt], sa[r], acc[0][nt][r]), rstd[nt], ca[r]);
+                    v[4 + r] = fmaf(fmaf(-mean[nt], sb[r], acc[1][nt][r]), rstd[nt], cc[r]);
+                }
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                *reinterpret_cast<u32x4*>(rrow + ((size_t)cb * TW + 16 * nt + n_) * 16) = in[nt] ? pack8(v) : z;
+            }
+        }
+    };
+    // phase D for output rows y, y + 1 (ring holds rows y-1 .. y+2)
+    auto dw_rows = [&](int y) {
+#pragma unroll
+        for (int j = 0; j < CBW; ++j) {
+            const int cb = wave + 4 * j;
+            if (cb >= Mb) break;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s3 = 0; s3 < 3; ++s3) {
+                    const char* src = ring + ((size_t)((y + drow[s3]) & 3) * Mb + cb) * (TW * 16) + dcol[s3][nt] * 16;
+                    const bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(src);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dwa[j][s3], bfrag, acc, 0, 0, 0);
+                }
+                const int col = 16 * nt + n_, x = x0 + col, yo = y + (gq >> 1);
+                if (col >= 1 && col <= 30 && x < W && yo < y_end) {
+                    const int64_t px = (int64_t)yo * W + x;
+                    if (GATE) {
+                        const uint32_t o = pack_bf16(pk_gelu(acc[0] + dbias[j][0]) * (acc[1] + dbias[j][1]),
+                                                     pk_gelu(acc[2] + dbias[j][2]) * (acc[3] + dbias[j][3]));
+                        *reinterpret_cast<uint32_t*>(Yb + (((int64_t)(cb >> 1) * N + px) * 16 + (cb & 1) * 8 + (gq & 1) * 4)) = o;
+                    } else {
+                        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                        u32x2 o;
+                        o[0] = pack_bf16(acc[0] + dbias[j][0], acc[1] + dbias[j][1]);
+                        o[1] = pack_bf16(acc[2] + dbias[j][2], acc[3] + dbias[j][3]);
+                        *reinterpret_cast<u32x2*>(Yb + (((int64_t)cb * N + px) * 16 + (gq & 1) * 8)) = o;
+                    }
+                }
+            }
+        }
+    };
+
+    bf16x8 xa[KS][2], xb[KS][2];
+    const int r0 = y_begin - 1;
+    xload(xa, r0); xload(xb, r0 + 1);
+    gemm_row(xa, r0); gemm_row(xb, r0 + 1);
+    xload(xa, r0 + 2); xload(xb, r0 + 3);
+    for (int y = y_begin; y < y_end; y += 2) {
+        gemm_row(xa, y + 1); gemm_row(xb, y + 2);
+        if (y + 2 < y_end) { xload(xa, y + 3); xload(xb, y + 4); }       // lands during phase D
+        __syncthreads();
+        dw_rows(y);
+        __syncthreads();
+    }
+}
+
 bool pwdw_pk_supported(int Kb, int W, int H) { return gemm_pk_ks(Kb) > 0 && gemm_pk_ks(Kb) <= 3 && W >= 16 && H >= 6; }
 
 int pwdw_pk_launch(PwDwPk g, hipStream_t stream) {
@@ -761,6 +960,40 @@ int pwdw_pk_launch(PwDwPk g, hipStream_t stream) {
     RST_REQUIRE(g.A && g.X && g.Y && g.ln_s && g.ln_c && g.dww, "bf16 fused 1x1 + depthwise: null operand");
     RST_REQUIRE(aligned16(g.A) && aligned16(g.X) && aligned16(g.Y) && aligned16(g.dww), "bf16 fused 1x1 + depthwise: operands must be 16-byte aligned");
     RST_REQUIRE(g.B <= 65535, "bf16 fused 1x1 + depthwise: batch %d exceeds 65535", g.B);
+    {
+        // the ring form: all channels in one block, 32-column strips; LDS = weights + constants + 4 rows of chunks
+        const int npairs = (int)cdiv(g.Mb, 4), cbw = (int)cdiv(g.Mb, 4);
+        const size_t lds = (size_t)npairs * 2 * KS * 1024 + (size_t)npairs * 32 * 2 * sizeof(float) + (size_t)4 * g.Mb * 32 * 16;
+        // not routed by default: with one block of four waves per CU every latency of the two phases is exposed
+        // (16 x 96 x 256^2 qkv: 900 us against 398 us for the register form and 420 us for the two kernels;
+        // 16 x 48 x 256^2: 223 against 212 us).  RST_BF16_RING=1 selects it (tests)
+        static const int ring_mode = getenv("RST_BF16_RING") ? atoi(getenv("RST_BF16_RING")) : 0;
+        if (ring_mode && lds <= 160 * 1024 && cbw <= 9 && g.H >= 2) {
+            static bool attr_done = false;
+            if (!attr_done) {
+#define RING_ATTR(ks, cw, gt) RST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pwdw_ring_kernel<ks, cw, gt>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+                RING_ATTR(2, 5, false); RING_ATTR(2, 4, true); RING_ATTR(3, 9, false); RING_ATTR(3, 8, true);
+#undef RING_ATTR
+                attr_done = true;
+            }
+            g.rows = 32;
+            while (g.rows > 8 && (int64_t)cdiv(g.W, 30) * cdiv(g.H, g.rows) * g.B < 512) g.rows >>= 1;
+            const dim3 grid((unsigned)(cdiv(g.W, 30) * cdiv(g.H, g.rows)), 1, (unsigned)g.B);
+            const double px = (double)g.H * g.W * g.B;
+            const double mout = g.gate ? g.Mb * 4 : g.Mb * 8;
+            ProfScope prof(stream, g.gate ? "pk_pwdw_gate" : "pk_pwdw", px * g.Mb * 8 * (2.0 * g.Kb * 8 + 18.0), px * 2.0 * (g.Kb * 8 + mout));
+            bool launched = true;
+            if (KS == 2 && !g.gate && cbw <= 5) hipLaunchKernelGGL((pwdw_ring_kernel<2, 5, false>), grid, dim3(256), lds, stream, g);
+            else if (KS == 2 && g.gate && cbw <= 4) hipLaunchKernelGGL((pwdw_ring_kernel<2, 4, true>), grid, dim3(256), lds, stream, g);
+            else if (KS == 3 && !g.gate && cbw <= 9) hipLaunchKernelGGL((pwdw_ring_kernel<3, 9, false>), grid, dim3(256), lds, stream, g);
+            else if (KS == 3 && g.gate && cbw <= 8) hipLaunchKernelGGL((pwdw_ring_kernel<3, 8, true>), grid, dim3(256), lds, stream, g);
+            else launched = false;
+            if (launched) {
+                RST_LAUNCH_CHECK();
+                return RST_OK;
+            }
+        }
+    }
     g.pb = gemm_pk_pairs(g.Kb, g.Mb);
     g.ngroups = (int)cdiv(cdiv(g.Mb, 4), g.pb);
     const int RO = KS <= 2 ? 6 : 4;

@@ -179,7 +179,7 @@ struct PwDwPk {
     const float* dww;
     int K, Kb, Mb;                       // Mb: channel blocks of the intermediate
     int B, H, W; int gate;
-    int pb, ngroups, patches_per_block;  // filled by the launcher
+    int pb, ngroups, patches_per_block, rows;  // filled by the launcher
 };
 bool pwdw_pk_supported(int Kb, int W, int H);
 int pwdw_pk_launch(PwDwPk g, hipStream_t stream);
