@@ -760,10 +760,10 @@ pwdw_pk_kernel(const PwDwPk g) {
 // convolution's B operand wants them.  Phase D (every second row): the depthwise convolution of two output rows
 // as in dwm_pk_kernel, its operand chunks read from the ring with ds_read_b128, the tap matrices of the wave's
 // channel blocks resident in registers.  The intermediate never leaves the CU, nothing is unpacked, and the vector
-// unit only runs the two epilogues.  A wave takes every fourth tile pair in G and every fourth channel block in D.
+// unit only runs the two epilogues.  A wave takes every NWV-th tile pair in G and every NWV-th channel block in D.
 // grid = (strips * row ranges, 1, samples)
-template <int KS, int CBW, bool GATE>
-__global__ void __launch_bounds__(256)
+template <int KS, int CBW, bool GATE, int NWV>
+__global__ void __launch_bounds__(64 * NWV)
 pwdw_ring_kernel(const PwDwPk g) {
     constexpr int TW = 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -777,8 +777,8 @@ pwdw_ring_kernel(const PwDwPk g) {
     {
         const u32x4* src = reinterpret_cast<const u32x4*>(g.A);
         u32x4* dst = reinterpret_cast<u32x4*>(smem);
-        for (int i = tid; i < npairs * 2 * KS * 64; i += 256) dst[i] = src[i];
-        for (int i = tid; i < npairs * 32; i += 256) { sc[i] = g.ln_s[i]; sc[npairs * 32 + i] = g.ln_c[i]; }
+        for (int i = tid; i < npairs * 2 * KS * 64; i += 64 * NWV) dst[i] = src[i];
+        for (int i = tid; i < npairs * 32; i += 64 * NWV) { sc[i] = g.ln_s[i]; sc[npairs * 32 + i] = g.ln_c[i]; }
     }
     const int H = g.H, W = g.W;
     const int64_t N = (int64_t)H * W;
@@ -793,13 +793,13 @@ pwdw_ring_kernel(const PwDwPk g) {
     const int Kb = g.Kb;
     auto pos_of = [](int q) { return GATE ? ((q & 1) ? 4 + (q >> 1) : (q >> 1)) : q; };
 
-    // tap matrices of this wave's channel blocks (cb = wave + 4 j), as in dwm_pk_kernel, and the biases of the
+    // tap matrices of this wave's channel blocks (cb = wave + NWV j), as in dwm_pk_kernel, and the biases of the
     // lane's 4 accumulator rows
     bf16x8 dwa[CBW][3];
     float dbias[CBW][4];
 #pragma unroll
     for (int j = 0; j < CBW; ++j) {
-        const int cb = wave + 4 * j;
+        const int cb = wave + NWV * j;
         const float* wl = g.dww + (cb < Mb ? cb : 0) * 80;
         const int m = n_, orow = m >> 3, p = pos_of(m & 7);
 #pragma unroll
@@ -870,7 +870,7 @@ pwdw_ring_kernel(const PwDwPk g) {
             in[nt] = ry >= 0 && ry < H && x >= 0 && x < W;
         }
         char* rrow = ring + (size_t)(ry & 3) * Mb * (TW * 16);
-        for (int p = wave; p < npairs; p += 4) {
+        for (int p = wave; p < npairs; p += NWV) {
             f32x4 acc[2][2];
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -908,7 +908,7 @@ pwdw_ring_kernel(const PwDwPk g) {
     auto dw_rows = [&](int y) {
 #pragma unroll
         for (int j = 0; j < CBW; ++j) {
-            const int cb = wave + 4 * j;
+            const int cb = wave + NWV * j;
             if (cb >= Mb) break;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
@@ -962,17 +962,16 @@ int pwdw_pk_launch(PwDwPk g, hipStream_t stream) {
     RST_REQUIRE(g.B <= 65535, "bf16 fused 1x1 + depthwise: batch %d exceeds 65535", g.B);
     {
         // the ring form: all channels in one block, 32-column strips; LDS = weights + constants + 4 rows of chunks
-        const int npairs = (int)cdiv(g.Mb, 4), cbw = (int)cdiv(g.Mb, 4);
+        const int npairs = (int)cdiv(g.Mb, 4), cbw = (int)cdiv(g.Mb, 8);        // 8 waves per block
         const size_t lds = (size_t)npairs * 2 * KS * 1024 + (size_t)npairs * 32 * 2 * sizeof(float) + (size_t)4 * g.Mb * 32 * 16;
-        // not routed by default: with one block of four waves per CU every latency of the two phases is exposed
-        // (16 x 96 x 256^2 qkv: 900 us against 398 us for the register form and 420 us for the two kernels;
-        // 16 x 48 x 256^2: 223 against 212 us).  RST_BF16_RING=1 selects it (tests)
+        // not routed by default: the two barrier-separated phases expose their latencies (see the numbers in the
+        // design notes).  RST_BF16_RING=1 selects it (tests)
         static const int ring_mode = getenv("RST_BF16_RING") ? atoi(getenv("RST_BF16_RING")) : 0;
-        if (ring_mode && lds <= 160 * 1024 && cbw <= 9 && g.H >= 2) {
+        if (ring_mode && lds <= 160 * 1024 && cbw <= 5 && g.H >= 2) {
             static bool attr_done = false;
             if (!attr_done) {
-#define RING_ATTR(ks, cw, gt) RST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pwdw_ring_kernel<ks, cw, gt>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-                RING_ATTR(2, 5, false); RING_ATTR(2, 4, true); RING_ATTR(3, 9, false); RING_ATTR(3, 8, true);
+#define RING_ATTR(ks, cw, gt) RST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pwdw_ring_kernel<ks, cw, gt, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+                RING_ATTR(2, 3, false); RING_ATTR(2, 2, true); RING_ATTR(3, 5, false); RING_ATTR(3, 4, true);
 #undef RING_ATTR
                 attr_done = true;
             }
@@ -983,10 +982,10 @@ int pwdw_pk_launch(PwDwPk g, hipStream_t stream) {
             const double mout = g.gate ? g.Mb * 4 : g.Mb * 8;
             ProfScope prof(stream, g.gate ? "pk_pwdw_gate" : "pk_pwdw", px * g.Mb * 8 * (2.0 * g.Kb * 8 + 18.0), px * 2.0 * (g.Kb * 8 + mout));
             bool launched = true;
-            if (KS == 2 && !g.gate && cbw <= 5) hipLaunchKernelGGL((pwdw_ring_kernel<2, 5, false>), grid, dim3(256), lds, stream, g);
-            else if (KS == 2 && g.gate && cbw <= 4) hipLaunchKernelGGL((pwdw_ring_kernel<2, 4, true>), grid, dim3(256), lds, stream, g);
-            else if (KS == 3 && !g.gate && cbw <= 9) hipLaunchKernelGGL((pwdw_ring_kernel<3, 9, false>), grid, dim3(256), lds, stream, g);
-            else if (KS == 3 && g.gate && cbw <= 8) hipLaunchKernelGGL((pwdw_ring_kernel<3, 8, true>), grid, dim3(256), lds, stream, g);
+            if (KS == 2 && !g.gate && cbw <= 3) hipLaunchKernelGGL((pwdw_ring_kernel<2, 3, false, 8>), grid, dim3(512), lds, stream, g);
+            else if (KS == 2 && g.gate && cbw <= 2) hipLaunchKernelGGL((pwdw_ring_kernel<2, 2, true, 8>), grid, dim3(512), lds, stream, g);
+            else if (KS == 3 && !g.gate && cbw <= 5) hipLaunchKernelGGL((pwdw_ring_kernel<3, 5, false, 8>), grid, dim3(512), lds, stream, g);
+            else if (KS == 3 && g.gate && cbw <= 4) hipLaunchKernelGGL((pwdw_ring_kernel<3, 4, true, 8>), grid, dim3(512), lds, stream, g);
             else launched = false;
             if (launched) {
                 RST_LAUNCH_CHECK();
