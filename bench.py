@@ -262,6 +262,26 @@ def main():
         "config": {"workload": workload, "global_batch": world * B, "input_hw": [Hh, Ww] if args.mode in ("tiled", "frame", "frame_sharded") else [S, S], "parallelism": {"tiled": f"tiles{world}", "frame_sharded": f"rows{world}"}.get(args.mode, f"dp{world}"),
                    "weights": "default init, seed 0"},
     }
+    if args.mode == "infer" and args.dtype == "f32":
+        # the same workload on the bf16 storage path (bf16 activations between kernels, fp32 sums), timed the same
+        # way; reported beside the fp32 line, never as `value`
+        xb = x.bfloat16()
+
+        def step_bf16():
+            with torch.no_grad():
+                return net(xb)
+        for _ in range(args.warmup):
+            step_bf16()
+        barrier(world)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_bf16()
+        barrier(world)
+        el = max_over_ranks(time.perf_counter() - t0, world)
+        out["bf16_storage"] = {"value": round(world * B * S * S * args.steps / 1e6 / el, 3), "unit": "MP/s",
+                               "ms_per_step": round(el / args.steps * 1e3, 3), "dtype": "bf16",
+                               "note": "same workload, activations stored in bf16 between kernels, fp32 sums and parameters; "
+                                       "PSNR within 0.01 dB of the fp32 result (tests/test_gpu_bf16.py)"}
     if rank != 0 and args.mode in ("train", "tiled", "frame_sharded"):
         step()          # the profiled extra step on rank 0 contains collectives: every rank takes part
     if rank == 0:
