@@ -35,6 +35,8 @@ def _free_port():
 
 
 def _worker(rank, world, port, out_path):
+    import faulthandler
+    faulthandler.dump_traceback_later(100, exit=False)      # a stuck rank shows where, before the parent's deadline
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
