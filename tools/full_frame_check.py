@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """One untiled full frame (default 1 x 3 x 2160 x 3840, fp32) through the HIP network on one GPU:
 time, peak memory, and the result against the CPU oracle on the same input.
-usage: python tools/full_frame_check.py [H W] [--no-oracle]"""
+usage: python tools/full_frame_check.py [H W] [--no-oracle] [--bf16]
+--bf16: the same frame on the bf16 storage path as well, against the fp32 result of this library (PSNR against a
+synthetic target within 0.01 dB, largest deviation, time, peak memory)."""
 import os
 import sys
 import time
@@ -28,6 +30,25 @@ def main():
         dt = time.perf_counter() - t0
     print(f"frame {H}x{W}: {dt*1e3:.1f} ms, {H*W/dt/1e6:.2f} MP/s, peak HBM {torch.cuda.max_memory_allocated()/2**30:.1f} GiB, "
           f"finite={bool(torch.isfinite(got).all())}", flush=True)
+    if "--bf16" in sys.argv:
+        import math
+        xb = xg.bfloat16()
+        with torch.no_grad():
+            net(xb)
+            torch.cuda.synchronize()
+            torch.cuda.reset_peak_memory_stats()
+            t0 = time.perf_counter()
+            gb = net(xb)
+            torch.cuda.synchronize()
+            dtb = time.perf_counter() - t0
+        target = (got + 0.03 * torch.randn(got.shape, device=got.device, generator=torch.Generator(device=got.device).manual_seed(1))).clamp(0, 1)
+
+        def psnr(a):
+            return 10.0 * math.log10(1.0 / float(((a.double() - target.double()) ** 2).mean()))
+        dev = float((gb.float() - got).abs().max() / got.abs().max())
+        print(f"bf16 storage: {dtb*1e3:.1f} ms, {H*W/dtb/1e6:.2f} MP/s, peak HBM {torch.cuda.max_memory_allocated()/2**30:.1f} GiB, "
+              f"max deviation from fp32 {dev:.3e}, PSNR {psnr(gb.float()):.4f} dB vs {psnr(got):.4f} dB (fp32)", flush=True)
+        assert abs(psnr(gb.float()) - psnr(got)) < 0.01 and dev < 2e-2
     if "--no-oracle" in sys.argv:
         return
     from oracle import restormer_oracle as orc
