@@ -268,15 +268,24 @@ gemm_pk_kernel(const GemmPk g) {
         }
     };
 
-    bf16x8 t0[KS][NT], t1[KS][NT];
     const int64_t first = p0 + (int64_t)wave * TILE;
-    load(t0, first);
-    for (int64_t n0 = first; n0 < p1; n0 += 8 * TILE) {
-        load(t1, n0 + 4 * TILE);
-        body(t0, n0);
-        if (n0 + 4 * TILE < p1) {
-            load(t0, n0 + 8 * TILE);
-            body(t1, n0 + 4 * TILE);
+    if constexpr (KS * NT <= 12) {
+        bf16x8 t0[KS][NT], t1[KS][NT];
+        load(t0, first);
+        for (int64_t n0 = first; n0 < p1; n0 += 8 * TILE) {
+            load(t1, n0 + 4 * TILE);
+            body(t0, n0);
+            if (n0 + 4 * TILE < p1) {
+                load(t0, n0 + 8 * TILE);
+                body(t1, n0 + 4 * TILE);
+            }
+        }
+    } else {
+        // many input channels: one operand buffer, but a weight fragment read from LDS serves more pixel tiles
+        bf16x8 t0[KS][NT];
+        for (int64_t n0 = first; n0 < p1; n0 += 4 * TILE) {
+            load(t0, n0);
+            body(t0, n0);
         }
     }
 }
@@ -315,7 +324,7 @@ int gemm_pk_launch(GemmPk g, hipStream_t stream) {
     RST_REQUIRE(g.B <= 65535, "bf16 1x1 convolution: batch %d exceeds 65535", g.B);
     g.pb = gemm_pk_pairs(g.Kb, g.Mb);
     g.ngroups = (int)cdiv(cdiv(g.Mb, 4), g.pb);
-    const int NT = KS <= 3 ? 4 : (KS <= 6 ? 2 : 1);
+    const int NT = KS <= 3 || KS == 6 ? 4 : 2;
     const int tile4 = 4 * 16 * NT;                       // pixels the four waves of a block take per round
     // about two blocks per CU over the chip, each at least two rounds long
     int64_t chunk = round_up(cdiv(g.N * g.B * g.ngroups, 512), tile4);
@@ -333,10 +342,10 @@ int gemm_pk_launch(GemmPk g, hipStream_t stream) {
         case 2: return gemm_pk_go<2, 4>(g, stream, grid, lds);
         case 3: return gemm_pk_go<3, 4>(g, stream, grid, lds);
         case 4: return gemm_pk_go<4, 2>(g, stream, grid, lds);
-        case 6: return gemm_pk_go<6, 2>(g, stream, grid, lds);
-        case 8: return gemm_pk_go<8, 1>(g, stream, grid, lds);
-        case 12: return gemm_pk_go<12, 1>(g, stream, grid, lds);
-        case 15: return gemm_pk_go<15, 1>(g, stream, grid, lds);
+        case 6: return gemm_pk_go<6, 4>(g, stream, grid, lds);
+        case 8: return gemm_pk_go<8, 2>(g, stream, grid, lds);
+        case 12: return gemm_pk_go<12, 2>(g, stream, grid, lds);
+        case 15: return gemm_pk_go<15, 2>(g, stream, grid, lds);
     }
     return fail(RST_ERR_INVALID, "bf16 1x1 convolution: no kernel for KS=%d", KS);
 }
