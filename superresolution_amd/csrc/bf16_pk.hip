@@ -566,10 +566,13 @@ int dw_pk_launch(DwPk a, hipStream_t stream) {
     RST_REQUIRE(a.W % 2 == 0 && a.W >= 2, "bf16 depthwise: width %d must be even", a.W);
     RST_REQUIRE(a.B <= 65535 && a.Cb <= 65535, "bf16 depthwise: batch or channel count exceeds 65535");
     // rows per strip: long strips re-read fewer halo rows; short ones give the chip enough threads
-    static const int mfma_mode = getenv("RST_DW_MFMA") ? atoi(getenv("RST_DW_MFMA")) : 0;     // bit 0: plain, bit 1: gated
-    if ((a.gate && (mfma_mode & 2)) || (!a.gate && (mfma_mode & 1))) {
-        static const int mrows = getenv("RST_DW_MROWS") ? atoi(getenv("RST_DW_MROWS")) : 32;
-        a.rows = mrows;
+    // RST_DW_MFMA: bit 0 forces the matrix-pipe kernel for the plain, bit 1 for the gated convolution (tests); unset,
+    // it takes the gated convolution of small images, where it was measured ahead (16 x 192 x 64^2: 32 vs 38 us,
+    // 16 x 384 x 32^2: 22 vs 29 us; 16 x 96 x 256^2: 251 vs 220 us)
+    static const int mfma_mode = getenv("RST_DW_MFMA") ? atoi(getenv("RST_DW_MFMA")) : -1;
+    const bool small_gate = mfma_mode < 0 && a.gate && (int64_t)a.H * a.W <= 64 * 64;
+    if (small_gate || (mfma_mode > 0 && ((a.gate && (mfma_mode & 2)) || (!a.gate && (mfma_mode & 1))))) {
+        a.rows = 32;
         const dim3 grid((unsigned)(cdiv(a.W, 64) * cdiv(a.H, a.rows)), a.Cb, a.B);
         const double el = (double)a.B * a.Cb * 8 * a.H * a.W;
         ProfScope prof(stream, a.gate ? "pk_dw_gate" : "pk_dw", el * 18.0, el * 2.0 * (a.gate ? 1.5 : 2.0));
