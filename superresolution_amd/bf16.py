@@ -124,10 +124,15 @@ def conv1x1(p: Packed, weight: torch.Tensor, bias: Optional[torch.Tensor] = None
 
 class PreparedCache:
     """Prepared weights of one block (rst_bf16_block_prepare), rebuilt when a parameter tensor is replaced or
-    modified in place (torch bumps ``_version`` on every in-place write)."""
+    modified in place (torch bumps ``_version`` on every in-place write, including optimizer steps, ``copy_`` and
+    ``load_state_dict``).  A write through ``param.data`` does NOT move ``_version``: call :meth:`invalidate` (or
+    ``Restormer.invalidate_prepared()``) after such a write."""
     __slots__ = ("key", "blob")
 
     def __init__(self):
+        self.key, self.blob = None, None
+
+    def invalidate(self):
         self.key, self.blob = None, None
 
     def get(self, lib, desc, par, params, device):

@@ -7,7 +7,10 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
+#include <tuple>
 
 #include "../../include/restormer_hip.h"
 
@@ -58,6 +61,31 @@ inline int fail(int code, const char* fmt, ...) {
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline int64_t round_up(int64_t a, int64_t b) { return cdiv(a, b) * b; }
+
+// ---- per-(device, kernel) launch set-up, asked once -----------------------------
+// CU count, the dynamic-LDS attribute and the occupancy of a kernel do not change between launches; the runtime
+// calls behind them cost host time on every launch and are not allowed while a stream is being captured.
+struct KernelSetup { int cus = 0, per_cu = 0; };
+inline int kernel_setup(const void* kern, int threads, size_t lds, KernelSetup* out) {
+    static std::mutex mu;
+    static std::map<std::tuple<int, const void*, size_t>, KernelSetup> seen;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return fail(RST_ERR_HIP, "hipGetDevice failed: %s", hipGetErrorString(e));
+    std::lock_guard<std::mutex> lock(mu);
+    KernelSetup& slot = seen[std::make_tuple(dev, kern, lds)];
+    if (slot.cus == 0) {
+        int cus = 256, per_cu = 1;
+        e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e == hipSuccess && lds > 64 * 1024)
+            e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds);
+        if (e != hipSuccess) return fail(RST_ERR_HIP, "kernel set-up failed: %s", hipGetErrorString(e));
+        slot.cus = cus; slot.per_cu = per_cu < 1 ? 1 : per_cu;
+    }
+    *out = slot;
+    return RST_OK;
+}
 
 // ---- optional per-kernel timing (prof.hip) -------------------------------------
 bool prof_enabled();

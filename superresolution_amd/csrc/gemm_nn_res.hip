@@ -295,9 +295,7 @@ int gemm_nn_res_try(const GemmNN& g, hipStream_t stream, bool* launched) {
     if (mblocks > 4) return RST_OK;
     const int ksm = g.K / 4;
 
-    int dev = 0, cus = 256;
-    RST_HIP(hipGetDevice(&dev));
-    RST_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    int cus = 256;
     const size_t lds = (size_t)(2 * 4 * ksm * GR_BN + GR_SCRATCH + 2 * 32 * mt) * sizeof(float);   // scratch doubles as weight staging (16 x (K+1))
     int per_cu = 1;
     int groups = 0;
@@ -310,11 +308,9 @@ int gemm_nn_res_try(const GemmNN& g, hipStream_t stream, bool* launched) {
     do {                                                                                                      \
         auto kern = gemm_nn_res_kernel<MTV, KSV, false, false>;                                               \
         if constexpr (KSV == 12 || KSV == 24) { if (g.ln_mode != 0) kern = gemm_nn_res_kernel<MTV, KSV, false, true>; } \
-        if (lds > 64 * 1024)                                                                                  \
-            RST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                                  \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
-        RST_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, GR_THREADS, lds));                       \
-        if (per_cu < 1) per_cu = 1;                                                                           \
+        KernelSetup su;                                                                                       \
+        RST_TRY(kernel_setup(reinterpret_cast<const void*>(kern), GR_THREADS, lds, &su));                     \
+        cus = su.cus; per_cu = su.per_cu;                                                                     \
         if (per_cu > 2) per_cu = 2;                                                                           \
         groups = cus * per_cu / mblocks;                                                                      \
         groups -= groups % 8;                                                                                 \

@@ -600,9 +600,6 @@ int pwdw_launch(const PwDw& a, hipStream_t stream) {
     RST_REQUIRE(a.X && a.A && a.dw_w && a.Y && a.B > 0 && a.M > 0, "pwdw: bad operand");
     RST_REQUIRE(a.ln_mode == 0 || (a.ln_s && a.ln_c), "pwdw: folded LayerNorm without its constants");
 
-    int dev = 0, cus = 256;
-    RST_HIP(hipGetDevice(&dev));
-    RST_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const void* kern = nullptr;
 #define PW_KS(NWV, GT, PP) do { if (p.ks == 12) kern = reinterpret_cast<const void*>(&pwdw_kernel<12, NWV, GT, false, PP, pw_ck(48)>); \
                                 else kern = reinterpret_cast<const void*>(&pwdw_kernel<24, NWV, GT, false, PP, pw_ck(96)>); } while (0)
@@ -612,10 +609,9 @@ int pwdw_launch(const PwDw& a, hipStream_t stream) {
 #undef PW_KS
     const size_t lds = sizeof(float) * (size_t)(pw_stages(pw_ck(a.K)) * pw_xch(pw_ck(a.K)) + 256 + 4 * PW_ROWF +
                                                 (a.gate ? (p.nw / 2) * 2 * (PW_T / 2) * 256 : 0) + p.nw * p.ks * 64 + 256);
-    if (lds > 64 * 1024) RST_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int per_cu = 1;
-    RST_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, p.nw * 64, lds));
-    if (per_cu < 1) per_cu = 1;
+    KernelSetup su;
+    RST_TRY(kernel_setup(kern, p.nw * 64, lds, &su));
+    const int cus = su.cus, per_cu = su.per_cu;
     // Split the rows of every (sample, strip, channel group) column so that the grid comes in whole
     // rounds of resident blocks; every row range recomputes two halo rows, so weigh that against
     // the fill of the last round.

@@ -5,6 +5,7 @@
 // (packed temporaries push its 128-register vector waves into spilling).
 #include "pwdw_ws_kernel.hpp"
 
+
 namespace rst {
 
 const void* pwdw_ws_gate_kernel(int ks);       // pwdw_ws_gate.hip
@@ -31,28 +32,33 @@ int pwdw_ws_launch(const PwDw& a, hipStream_t stream) {
     const int KS = a.K / 4;
     const int NM = a.gate ? 8 : (a.K == 96 ? 6 : 3);
     const int nstrips = (int)cdiv(a.W, WS_WT), G = a.gate ? (int)cdiv(cdiv(a.hidden, 16), 4) : a.M / (16 * NM);
-    int dev = 0, cus = 256;
-    RST_HIP(hipGetDevice(&dev));
-    RST_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     const void* kern = a.gate ? pwdw_ws_gate_kernel(KS)
                      : KS == 24 ? reinterpret_cast<const void*>(&pwdw_ws_kernel<24, 6, false>)
                                 : reinterpret_cast<const void*>(&pwdw_ws_kernel<12, 3, false>);
     const size_t lds = sizeof(float) * (size_t)(WS_STAGES * ws_xch(KS) + 256 + 4 * WS_ROWF + NM * WS_T * 256 + NM * 2 * 64 + NM * KS * 64);
-    RST_HIP(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int per_cu = 1;
-    RST_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, NM * 128, lds));
-    if (per_cu < 1) per_cu = 1;
+    KernelSetup su;
+    RST_TRY(kernel_setup(kern, NM * 128, lds, &su));
+    static std::mutex mu;
+    static std::map<std::tuple<int64_t, int, int64_t>, int> nsplits;      // (columns x groups, H, slots) -> row split
     // rows of every (sample, strip, channel group) column split so that the grid comes in whole rounds of
     // resident blocks (one per CU); every row range recomputes two halo rows
-    const int64_t cols0 = (int64_t)a.B * nstrips, slots = (int64_t)cus * per_cu;
+    const int64_t cols0 = (int64_t)a.B * nstrips, slots = (int64_t)su.cus * su.per_cu;
     int nsplit = 1;
-    double best = -1.0;
-    for (int ns = 1; ns <= (a.H >= 16 ? a.H / 8 : 1); ++ns) {
-        const int64_t blocks = cols0 * G * ns;
-        const int64_t rounds = cdiv(blocks, slots);
-        const double rows = (double)a.H / ns;
-        const double eff = (double)blocks / (double)(rounds * slots) * rows / (rows + 3.0);
-        if (eff > best + 1e-9) { best = eff; nsplit = ns; }
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        int& memo = nsplits[{cols0 * G, a.H, slots}];
+        if (memo == 0) {
+            double best = -1.0;
+            memo = 1;
+            for (int ns = 1; ns <= (a.H >= 16 ? a.H / 8 : 1); ++ns) {
+                const int64_t blocks = cols0 * G * ns;
+                const int64_t rounds = cdiv(blocks, slots);
+                const double rows = (double)a.H / ns;
+                const double eff = (double)blocks / (double)(rounds * slots) * rows / (rows + 3.0);
+                if (eff > best + 1e-9) { best = eff; memo = ns; }
+            }
+        }
+        nsplit = memo;
     }
     const int64_t ncols64 = cols0 * nsplit;
     RST_REQUIRE(ncols64 * G < (1ll << 30), "pwdw_ws: grid too large");

@@ -231,6 +231,21 @@ class Restormer(nn.Module):
             self.skip_conv = nn.Conv2d(dim, w2, kernel_size=1, bias=bias)
         self.output = nn.Conv2d(dim, out_channels, kernel_size=3, stride=1, padding=1, bias=bias)
 
+    def invalidate_prepared(self):
+        """Drop the prepared bf16 weights of every block (needed only after parameter writes that bypass torch's
+        version counter, i.e. through ``param.data``)."""
+        for m in self.modules():
+            cache = getattr(m, "_pk_cache", None)
+            if cache is not None:
+                cache.invalidate()
+
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .float() / .cuda() may replace parameter storage behind the same version number
+        out = super()._apply(fn, *args, **kwargs)
+        self.invalidate_prepared()
+        self._bf16_widths_ok = None
+        return out
+
     def _forward_bf16(self, inp_img):
         """Inference with bf16 activations (a bf16 input, or an fp32 input under bf16 autocast): every
         TransformerBlock and 1x1 convolution runs on the library's channel-packed bf16 tensors with fp32 sums
@@ -294,7 +309,40 @@ class Restormer(nn.Module):
             raise RuntimeError(f"Restormer needs H and W divisible by 8, got {tuple(inp_img.shape[-2:])}")
         if inp_img.dtype == torch.bfloat16 or (inp_img.is_cuda and torch.is_autocast_enabled()
                                                and torch.get_autocast_dtype("cuda") == torch.bfloat16):
-            return self._forward_bf16(inp_img)
+            if self._bf16_inference_ok(inp_img):
+                return self._forward_bf16(inp_img)
+            # Training, or a width the packed bf16 kernels do not serve (e.g. the default dim=12): the fp32 kernels
+            # on an fp32 copy of the input, result in the input's dtype -- the reference module runs under
+            # autocast through ordinary torch operators, so such a call must not fail.
+            with torch.autocast("cuda", enabled=False):
+                return self._forward_fp32(inp_img.float()).to(inp_img.dtype)
+        return self._forward_fp32(inp_img)
+
+    def _bf16_inference_ok(self, inp_img) -> bool:
+        """True when this call can run on the packed bf16 inference kernels: no autograd graph wanted, a ROCm
+        tensor, and every stage's (width, heads, hidden) supported by rst_bf16_block_fwd (asked once per module)."""
+        if torch.is_grad_enabled() and (inp_img.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return False
+        if not inp_img.is_cuda:
+            return False
+        ok = getattr(self, "_bf16_widths_ok", None)
+        if ok is None:
+            import ctypes
+            from .. import _lib
+            lib = _lib.load()
+            ok = True
+            for stage in (self.encoder_level1, self.encoder_level2, self.encoder_level3, self.latent, self.decoder_level3,
+                          self.decoder_level2, self.decoder_level1, self.refinement):
+                for blk in stage[:1]:
+                    c = blk.attn.qkv.in_channels
+                    desc = ops.make_desc(1, c, 16, 16, blk.attn.num_heads, blk.ffn.hidden_features,
+                                         blk.norm1.body.with_bias, blk.attn.qkv.bias is not None)
+                    ok = ok and c % 8 == 0 and lib.rst_bf16_block_workspace_bytes(ctypes.byref(desc)) != 0
+            ok = ok and lib.rst_bf16_conv1x1_workspace_bytes(self.reduce_chan_level3.in_channels, self.reduce_chan_level3.out_channels) != 0
+            self._bf16_widths_ok = bool(ok)
+        return ok
+
+    def _forward_fp32(self, inp_img):
         e1_in = self.patch_embed(inp_img)
         e1 = self.encoder_level1(e1_in)
         e2 = self.encoder_level2(self.down1_2(e1))

@@ -28,6 +28,10 @@ def _require(t: torch.Tensor, name: str) -> torch.Tensor:
     return t.contiguous()
 
 
+def _opt(t: Optional[torch.Tensor], name: str) -> Optional[torch.Tensor]:
+    return None if t is None else _require(t, name)
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -75,7 +79,10 @@ class _LayerNormFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         lib = _lib.load()
         x = _require(x, "layernorm x")
+        weight, bias = _require(weight, "layernorm weight"), _opt(bias, "layernorm bias")
         B, C, H, W = x.shape
+        if weight.numel() != C or (bias is not None and bias.numel() != C):
+            raise RuntimeError(f"layernorm: weight/bias must have {C} elements")
         y = torch.empty_like(x)
         check(lib.rst_layernorm_fwd(_ptr(x), _ptr(weight), _ptr(bias), _ptr(y), B, C, H * W, _stream()), "rst_layernorm_fwd")
         ctx.save_for_backward(x, weight)
@@ -111,8 +118,11 @@ class _Conv1x1Fn(torch.autograd.Function):
         lib = _lib.load()
         x = _require(x, "conv1x1 x")
         w = _require(weight, "conv1x1 weight")
+        bias = _opt(bias, "conv1x1 bias")
         B, Cin, H, W = x.shape
         Cout = w.shape[0]
+        if w.numel() != Cout * Cin or (bias is not None and bias.numel() != Cout):
+            raise RuntimeError(f"conv1x1: weight {tuple(w.shape)} / bias do not match {Cin} input channels")
         y = torch.empty((B, Cout, H, W), dtype=x.dtype, device=x.device)
         check(lib.rst_conv1x1_fwd(_ptr(x), _ptr(w), _ptr(bias), None, _ptr(y), B, Cin, Cout, H * W, _stream()), "rst_conv1x1_fwd")
         ctx.save_for_backward(x, w)
@@ -149,7 +159,10 @@ class _DwConvFn(torch.autograd.Function):
         lib = _lib.load()
         x = _require(x, "dwconv x")
         w = _require(weight, "dwconv weight")
+        bias = _opt(bias, "dwconv bias")
         B, C, H, W = x.shape
+        if w.numel() != C * 9 or (bias is not None and bias.numel() != C):
+            raise RuntimeError(f"dwconv: weight {tuple(w.shape)} / bias do not match {C} channels")
         y = torch.empty_like(x)
         check(lib.rst_dwconv3x3_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, C, H, W, _stream()), "rst_dwconv3x3_fwd")
         ctx.save_for_backward(x, w)
@@ -247,6 +260,9 @@ class _Conv3x3FewOutFn(torch.autograd.Function):
         if tuple(w.shape) != (Cout, Cin, 3, 3):
             raise RuntimeError(f"conv3x3: weight shape {tuple(w.shape)} does not match input channels {Cin}")
         res = None if residual is None else _require(residual, "conv3x3 residual")
+        bias = _opt(bias, "conv3x3 bias")
+        if bias is not None and bias.numel() != Cout:
+            raise RuntimeError(f"conv3x3: bias must have {Cout} elements")
         if res is not None and tuple(res.shape) != (B, Cout, H, W):
             raise RuntimeError(f"conv3x3: residual shape {tuple(res.shape)} != {(B, Cout, H, W)}")
         y = torch.empty((B, Cout, H, W), dtype=x.dtype, device=x.device)

@@ -25,6 +25,46 @@ import torch.nn.functional as F
 
 
 # ----------------------------------------------------------------------------
+# the exchanges the multi-GPU paths need
+# ----------------------------------------------------------------------------
+class Collectives:
+    """torch.distributed as it is: every buffer goes to the backend where it lives (RCCL moves device buffers
+    over xGMI directly; gloo moves host buffers).  The functions below take an object with this interface, so a
+    harness with other needs (several ranks on one card, where RCCL cannot run and gloo would have to stage
+    device buffers itself) passes its own."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def world_size(self) -> int:
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def all_reduce(self, t: torch.Tensor, op=dist.ReduceOp.SUM, async_op: bool = False):
+        """In-place reduction over the ranks; with `async_op` returns a handle whose wait() completes it."""
+        return dist.all_reduce(t, op=op, group=self.group, async_op=async_op)
+
+    def broadcast(self, t: torch.Tensor, src: int = 0) -> None:
+        dist.broadcast(t, src=src, group=self.group)
+
+    def exchange(self, pairs) -> None:
+        """pairs: (send tensor or None, receive tensor or None, peer) -- all transfers posted together, then
+        waited for.  Tensors must be contiguous."""
+        ops_ = []
+        for send, recv, peer in pairs:
+            if send is not None:
+                ops_.append(dist.P2POp(dist.isend, send, peer, self.group))
+            if recv is not None:
+                ops_.append(dist.P2POp(dist.irecv, recv, peer, self.group))
+        if ops_:
+            for q in dist.batch_isend_irecv(ops_):
+                q.wait()
+
+
+def _comm(comm: Optional[Collectives], process_group) -> Collectives:
+    return comm if comm is not None else Collectives(process_group)
+
+
+# ----------------------------------------------------------------------------
 # data-parallel training
 # ----------------------------------------------------------------------------
 class _Bucket:
@@ -63,10 +103,10 @@ class DataParallelTrainer:
     def __init__(self, model: nn.Module, world_size: Optional[int] = None, lr: float = 1e-4, weight_decay: float = 1e-6,
                  max_grad_norm: float = 1.0, bucket_mb: float = 25.0,
                  loss_fn: Callable[[torch.Tensor, torch.Tensor], torch.Tensor] = F.l1_loss,
-                 process_group=None):
+                 process_group=None, comm: Optional[Collectives] = None):
         self.model = model
-        self.group = process_group
-        self.world = world_size if world_size is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
+        self.comm = _comm(comm, process_group)
+        self.world = world_size if world_size is not None else self.comm.world_size()
         self.max_grad_norm = max_grad_norm
         self.loss_fn = loss_fn
         params = [p for p in model.parameters() if p.requires_grad]
@@ -92,7 +132,6 @@ class DataParallelTrainer:
             for i, (p, v) in enumerate(zip(b.params, b.views)):
                 p.grad = v
                 self._owner[p] = (b, i)
-        self._host_staged = self.world > 1 and dev.type == "cuda" and dist.get_backend(process_group) == "gloo"
         if self.world > 1:
             for p in params:
                 p.register_post_accumulate_grad_hook(self._on_grad_ready)
@@ -102,16 +141,15 @@ class DataParallelTrainer:
         """Make every rank start from rank 0's parameters."""
         if self.world > 1:
             ps = list(self.model.parameters())
-            flat = torch.cat([p.data.reshape(-1) for p in ps])        # one message instead of one per tensor
-            # gloo (tests, ranks sharing a card) has no usable device broadcast: through the host there
-            host = flat.is_cuda and dist.get_backend(self.group) == "gloo"
-            buf = flat.cpu() if host else flat
-            dist.broadcast(buf, src=0, group=self.group)
-            flat = buf.to(flat.device) if host else buf
-            off = 0
-            for p in ps:
-                p.data.copy_(flat[off:off + p.numel()].view_as(p.data))
-                off += p.numel()
+            with torch.no_grad():
+                flat = torch.cat([p.reshape(-1) for p in ps])         # one message instead of one per tensor
+                self.comm.broadcast(flat, src=0)
+                off = 0
+                for p in ps:
+                    # an in-place copy_ (not a write through .data) so that the parameter's version counter moves and
+                    # anything derived from the old values (prepared bf16 weights) is rebuilt
+                    p.copy_(flat[off:off + p.numel()].view_as(p))
+                    off += p.numel()
 
     def _on_grad_ready(self, p: nn.Parameter):
         b, i = self._owner[p]
@@ -121,8 +159,8 @@ class DataParallelTrainer:
             v.copy_(p.grad)
             p.grad = v
         b.pending -= 1
-        if b.pending == 0 and not self._host_staged:
-            b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if b.pending == 0:
+            b.handle = self.comm.all_reduce(b.flat, async_op=True)
 
     def zero_grad(self):
         for b in self.buckets:
@@ -136,18 +174,10 @@ class DataParallelTrainer:
         out = self.model(x)
         loss = self.loss_fn(out, target)
         loss.backward()
-        if self.world > 1 and self._host_staged:
-            # gloo with device buffers (tests: ranks sharing one card) -- large device collectives do not complete
-            # there, so the buckets go through the host, after the backward pass
-            for b in self.buckets:
-                tmp = b.flat.cpu()
-                dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=self.group)
-                b.flat.copy_(tmp)
-                b.flat.div_(self.world)
-        elif self.world > 1:
+        if self.world > 1:
             for b in self.buckets:
                 if b.handle is None:      # a parameter without gradient this step kept the bucket open
-                    b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    b.handle = self.comm.all_reduce(b.flat, async_op=True)
             for b in self.buckets:
                 b.handle.wait()
                 b.flat.div_(self.world)
@@ -183,7 +213,7 @@ def tile_grid(h: int, w: int, tile: int, overlap: int, multiple: int = 8) -> Lis
 @torch.no_grad()
 def tiled_inference(model: nn.Module, image: torch.Tensor, tile: int = 256, overlap: int = 32, scale: int = 2,
                     rank: int = 0, world: int = 1, tile_batch: int = 8, process_group=None,
-                    gather: bool = True) -> Optional[torch.Tensor]:
+                    gather: bool = True, comm: Optional[Collectives] = None) -> Optional[torch.Tensor]:
     """x`scale` inference of a 1 x C x H x W image in overlapping tiles.
 
     Tile t goes to rank t % world.  Each rank batches its same-shaped tiles
@@ -227,8 +257,9 @@ def tiled_inference(model: nn.Module, image: torch.Tensor, tile: int = 256, over
         return None
     # every rank sends its cores to rank 0 as one flat message (sizes are known from the grid)
     flat = torch.cat([results[i].reshape(-1) for i in sorted(results)]) if results else image.new_empty(0)
+    comm = _comm(comm, process_group)
     co = torch.tensor([c_out if c_out is not None else 0], device=image.device)
-    dist.all_reduce(co, op=dist.ReduceOp.MAX, group=process_group)
+    comm.all_reduce(co, op=dist.ReduceOp.MAX)
     c_out = int(co.item())
     sizes = []
     for r in range(world):
@@ -240,9 +271,7 @@ def tiled_inference(model: nn.Module, image: torch.Tensor, tile: int = 256, over
     if rank == 0:
         bufs = [torch.empty(n, dtype=image.dtype, device=image.device) for n in sizes]
         bufs[0] = flat
-        reqs = [dist.irecv(bufs[r], src=r, group=process_group) for r in range(1, world) if sizes[r] > 0]
-        for q in reqs:
-            q.wait()
+        comm.exchange([(None, bufs[r], r) for r in range(1, world) if sizes[r] > 0])
         canvas = torch.empty((1, c_out, h * scale, w * scale), dtype=image.dtype, device=image.device)
         for r in range(world):
             off = 0
@@ -255,7 +284,7 @@ def tiled_inference(model: nn.Module, image: torch.Tensor, tile: int = 256, over
                 off += n
         return canvas
     if sizes[rank] > 0:
-        dist.send(flat, dst=0, group=process_group)
+        comm.exchange([(flat, None, 0)])
     return None
 
 
@@ -302,30 +331,7 @@ class _Slab:
         return self.t[:, :, self.r0:self.r1]
 
 
-def _exchange(pairs, group):
-    """pairs: list of (send_tensor or None, recv_tensor or None, peer).  NCCL moves device buffers directly; gloo
-    (CPU tests, two ranks on one card) has no device point-to-point, so the rows are staged through the host."""
-    staged = dist.get_backend(group) == "gloo"
-    ops_, keep = [], []
-    for send, recv, peer in pairs:
-        if send is not None:
-            s = send.cpu() if staged else send
-            keep.append(s)
-            ops_.append(dist.P2POp(dist.isend, s, peer, group))
-        if recv is not None:
-            r = torch.empty(recv.shape, dtype=recv.dtype) if staged else recv
-            keep.append((r, recv))
-            ops_.append(dist.P2POp(dist.irecv, r, peer, group))
-    if ops_:
-        for q in dist.batch_isend_irecv(ops_):
-            q.wait()
-    if staged:
-        for k in keep:
-            if isinstance(k, tuple):
-                k[1].copy_(k[0])
-
-
-def _refresh_halo(s: _Slab, rank: int, world: int, group) -> None:
+def _refresh_halo(s: _Slab, rank: int, world: int, comm: Optional[Collectives]) -> None:
     """The halo rows of the slab <- the neighbours' outermost own rows (and the other way round)."""
     if world == 1:
         return
@@ -338,13 +344,13 @@ def _refresh_halo(s: _Slab, rank: int, world: int, group) -> None:
         dn = torch.empty_like(s.t[:, :, s.r1:])
         pairs.append((s.t[:, :, s.r1 - HALO:s.r1].contiguous(), dn, rank + 1))
         land.append((slice(s.r1, s.t.shape[2]), dn))
-    _exchange(pairs, group)
+    _comm(comm, None).exchange(pairs)
     for sl, buf in land:
         s.t[:, :, sl] = buf
 
 
 def sharded_frame_inference(model: nn.Module, image: torch.Tensor, rank: int = 0, world: int = 1, process_group=None,
-                            gather: bool = True) -> Optional[torch.Tensor]:
+                            gather: bool = True, comm: Optional[Collectives] = None) -> Optional[torch.Tensor]:
     """EXACT x2 inference of one 1 x C x H x W frame whose rows are split over `world` GPUs (same result as the
     network on the whole frame, up to summation order): each rank runs the network on its row slab plus two halo
     rows; inside every TransformerBlock the only global quantities -- the Gram matrices q.k^T and the squared
@@ -362,11 +368,12 @@ def sharded_frame_inference(model: nn.Module, image: torch.Tensor, rank: int = 0
         raise ValueError("W must be divisible by 8")
     cuts = row_partition(h, world)
     a, b = cuts[rank]
+    comm = _comm(comm, process_group)
 
     def slab(interior, factor_num, factor_den=1):
         """interior rows at the level whose row count is h * num / den"""
         s = _Slab(interior, a * factor_num // factor_den, b * factor_num // factor_den, h * factor_num // factor_den)
-        _refresh_halo(s, rank, world, process_group)
+        _refresh_halo(s, rank, world, comm)
         return s
 
     def stage(blocks, s: _Slab) -> _Slab:
@@ -374,9 +381,9 @@ def sharded_frame_inference(model: nn.Module, image: torch.Tensor, rank: int = 0
             heads, hidden, par = blk.attn.num_heads, blk.ffn.hidden_features, blk._params()
             stats = ops.block_shard_stats(s.t, s.r0, s.r1, heads, hidden, par)
             if world > 1:
-                dist.all_reduce(stats, group=process_group)
+                comm.all_reduce(stats)
             ops.block_shard_apply(s.t, stats, heads, hidden, par)
-            _refresh_halo(s, rank, world, process_group)
+            _refresh_halo(s, rank, world, comm)
         return s
 
     def conv(s: _Slab, c: nn.Conv2d) -> torch.Tensor:
@@ -427,9 +434,9 @@ def sharded_frame_inference(model: nn.Module, image: torch.Tensor, rank: int = 0
         canvas = mine.new_empty((1, mine.shape[1], 2 * h, 2 * w))
         canvas[:, :, 2 * a:2 * b] = mine
         bufs = [(canvas.new_empty((1, mine.shape[1], 2 * (cb - ca), 2 * w)), r) for r, (ca, cb) in enumerate(cuts) if r > 0]
-        _exchange([(None, buf, r) for buf, r in bufs], process_group)
+        comm.exchange([(None, buf, r) for buf, r in bufs])
         for buf, r in bufs:
             canvas[:, :, 2 * cuts[r][0]:2 * cuts[r][1]] = buf
         return canvas
-    _exchange([(mine, None, 0)], process_group)
+    comm.exchange([(mine, None, 0)])
     return None

@@ -29,19 +29,3 @@ def check_pin(store, key, t: torch.Tensor, rtol: float, what: str = ""):
     l2 = float(store[key + "/l2"])
     assert abs(np.sqrt((a * a).sum()) - l2) <= rtol * max(l2, 1e-30) * 4, (what, key, "l2 norm")
     return err
-
-
-def spawn_bounded(fn, args, nprocs, deadline_s=150.0):
-    """torch.multiprocessing.spawn that cannot hang: the workers are joined with a deadline and killed when it
-    passes (a stuck rendezvous or collective then fails this one test instead of stalling the whole run)."""
-    import time
-
-    import torch.multiprocessing as mp
-    ctx = mp.spawn(fn, args=args, nprocs=nprocs, join=False)
-    t_end = time.monotonic() + deadline_s
-    while not ctx.join(timeout=5.0):
-        if time.monotonic() > t_end:
-            for proc in ctx.processes:
-                if proc.is_alive():
-                    proc.kill()
-            raise AssertionError(f"{nprocs} worker processes did not finish within {deadline_s:.0f} s; killed")

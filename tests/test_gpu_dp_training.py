@@ -7,7 +7,7 @@ import sys
 
 import pytest
 
-from golden_util import spawn_bounded
+from dist_util import spawn_bounded
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -41,9 +41,10 @@ def _worker(rank, world, port, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    from dist_util import HostStagedCollectives
     from superresolution_amd.parallel import DataParallelTrainer
     net = _net()
-    trainer = DataParallelTrainer(net, bucket_mb=0.05)          # several buckets
+    trainer = DataParallelTrainer(net, bucket_mb=0.05, comm=HostStagedCollectives())          # several buckets
     assert len(trainer.buckets) > 1
     x, t = _data()
     xs, ts = x[rank * 2:(rank + 1) * 2], t[rank * 2:(rank + 1) * 2]
@@ -57,7 +58,7 @@ def _worker(rank, world, port, out_path):
 def test_two_ranks_match_one_process(tmp_path):
     from superresolution_amd.parallel import DataParallelTrainer
     out = str(tmp_path / "dp.pt")
-    spawn_bounded(_worker, (2, _free_port(), out), 2)
+    spawn_bounded(_worker, (2, _free_port(), out), 2, log_dir=tmp_path)
     got = torch.load(out, weights_only=True)
     net = _net()
     trainer = DataParallelTrainer(net, world_size=1)

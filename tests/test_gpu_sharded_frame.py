@@ -7,7 +7,7 @@ import sys
 
 import pytest
 
-from golden_util import spawn_bounded
+from dist_util import spawn_bounded
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -60,17 +60,51 @@ def _free_port():
         return s.getsockname()[1]
 
 
+@pytest.mark.parametrize("C,heads,H,W,world", [(96, 1, 64, 128, 3), (96, 1, 64, 128, 2), (48, 1, 64, 128, 3),
+                                                (96, 2, 32, 64, 3), (192, 4, 16, 32, 2)])
+def test_slab_kernels_in_one_process(C, heads, H, W, world):
+    """The two C-ABI phases of a block on every rank's slab (own rows + halo: 18/26/28 rows at H=64, world 3), run
+    one after the other in ONE process with the sums added by hand, against the block on the whole frame: the
+    kernels of the sharded path at exactly the slab shapes of the multi-process test, without any collective."""
+    from superresolution_amd import ops
+    from superresolution_amd.model.Restromer import TransformerBlock
+    from superresolution_amd.parallel import HALO, row_partition
+    torch.manual_seed(5)
+    blk = TransformerBlock(C, heads, 1.25, False, "WithBias").cuda().eval()
+    with torch.no_grad():
+        for n, p in blk.named_parameters():
+            if n.endswith("temperature") or ".body." in n:
+                p.copy_(torch.rand_like(p) + 0.5)
+    x = torch.randn(1, C, H, W, generator=torch.Generator().manual_seed(6)).cuda()
+    with torch.no_grad():
+        ref = blk(x)
+    par, hidden = blk._params(), blk.ffn.hidden_features
+    slabs, total = [], None
+    for a, b in row_partition(H, world, multiple=8):
+        lo, hi = max(a - HALO, 0), min(b + HALO, H)
+        t = x[:, :, lo:hi].contiguous()
+        st = ops.block_shard_stats(t, a - lo, b - lo, heads, hidden, par).clone()
+        total = st if total is None else total + st
+        slabs.append((a, b, lo, t))
+    for a, b, lo, t in slabs:
+        # phase 1 again: phase 2 expects this slab's qkv in the shared workspace
+        ops.block_shard_stats(t, a - lo, b - lo, heads, hidden, par)
+        y = ops.block_shard_apply(t, total, heads, hidden, par)
+        assert _rel(y[:, :, a - lo:b - lo], ref[:, :, a:b]) < 2e-6, (a, b)
+
+
 def _worker(rank, world, port, name, out_path):
     import faulthandler
     faulthandler.dump_traceback_later(100, exit=False)      # a stuck rank shows where, before the parent's deadline
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))      # both ranks share the one card: no RCCL here
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))      # the ranks share the one card: no RCCL here
+    from dist_util import HostStagedCollectives
     from superresolution_amd.parallel import sharded_frame_inference
     dim, h, w = CASES[name]
     net, x = _net(dim), _image(h, w)
-    out = sharded_frame_inference(net, x, rank, world)
+    out = sharded_frame_inference(net, x, rank, world, comm=HostStagedCollectives())
     if rank == 0:
         with torch.no_grad():
             ref = net(x)
@@ -85,7 +119,7 @@ def _worker(rank, world, port, name, out_path):
 @pytest.mark.parametrize("name", list(CASES))
 def test_ranks_on_one_card_equal_whole_frame(name, world, tmp_path):
     out_path = str(tmp_path / "r.pt")
-    spawn_bounded(_worker, (world, _free_port(), name, out_path), world)
+    spawn_bounded(_worker, (world, _free_port(), name, out_path), world, log_dir=tmp_path)
     r = torch.load(out_path)
     assert r["shape"] == r["ref_shape"]
     assert r["err"] < 2e-6, r

@@ -9,7 +9,7 @@ import socket
 
 import pytest
 
-from golden_util import spawn_bounded
+from dist_util import spawn_bounded
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
