@@ -133,12 +133,29 @@ def test_model_bf16_end_to_end_psnr():
     assert _maxrel(out_ac, ref) < BF16_TOL
 
 
-def test_bf16_path_refuses_training_and_cpu():
-    import bench
+def test_bf16_calls_outside_the_packed_path_run_the_fp32_kernels():
+    """The packed bf16 kernels serve inference at widths that are multiples of 8 with 16-multiple heads.  Any other
+    bf16 / autocast call -- the reference's default Restormer() (dim 12) under autocast, or a call that wants
+    gradients -- must still work, as it does with the reference module (ordinary torch ops under autocast): it
+    runs the fp32 kernels and returns the input's dtype."""
     from superresolution_amd import bf16
-    net = bench.build_model(0).cuda()
-    with pytest.raises(RuntimeError):
-        net(torch.rand(1, 3, 16, 16, device="cuda").bfloat16())      # grad mode on
+    from superresolution_amd.model.Restromer import Restormer
+    torch.manual_seed(2)
+    net = Restormer().cuda().eval()                                   # reference defaults: 4 channels, dim 12
+    x = torch.rand(1, 4, 16, 24, device="cuda")
+    with torch.no_grad():
+        ref = net(x)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            got = net(x)
+        got_bf = net(x.bfloat16())
+    assert got.dtype == torch.float32 and torch.equal(got, ref)
+    assert got_bf.dtype == torch.bfloat16 and _maxrel(got_bf.float(), ref) < BF16_TOL
+    # gradients wanted: fp32 kernels with autograd, also under autocast
+    net.train()
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = net(x)
+    out.float().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
     with pytest.raises(RuntimeError):
         bf16.pack(torch.rand(1, 8, 4, 4))                             # CPU tensor
 

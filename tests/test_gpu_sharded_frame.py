@@ -60,15 +60,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("C,heads,H,W,world", [(96, 1, 64, 128, 3), (96, 1, 64, 128, 2), (48, 1, 64, 128, 3),
-                                                (96, 2, 32, 64, 3), (192, 4, 16, 32, 2)])
-def test_slab_kernels_in_one_process(C, heads, H, W, world):
+@pytest.mark.parametrize("C,heads,d,world", [(96, 1, 1, 3), (96, 1, 1, 2), (48, 1, 1, 3), (96, 2, 2, 3), (192, 4, 4, 2)])
+def test_slab_kernels_in_one_process(C, heads, d, world):
     """The two C-ABI phases of a block on every rank's slab (own rows + halo: 18/26/28 rows at H=64, world 3), run
     one after the other in ONE process with the sums added by hand, against the block on the whole frame: the
     kernels of the sharded path at exactly the slab shapes of the multi-process test, without any collective."""
     from superresolution_amd import ops
     from superresolution_amd.model.Restromer import TransformerBlock
     from superresolution_amd.parallel import HALO, row_partition
+    H, W = 64 // d, 128 // d                       # level with down-sampling factor d of a 64 x 128 frame
     torch.manual_seed(5)
     blk = TransformerBlock(C, heads, 1.25, False, "WithBias").cuda().eval()
     with torch.no_grad():
@@ -80,7 +80,7 @@ def test_slab_kernels_in_one_process(C, heads, H, W, world):
         ref = blk(x)
     par, hidden = blk._params(), blk.ffn.hidden_features
     slabs, total = [], None
-    for a, b in row_partition(H, world, multiple=8):
+    for a, b in ((a0 // d, b0 // d) for a0, b0 in row_partition(64, world)):
         lo, hi = max(a - HALO, 0), min(b + HALO, H)
         t = x[:, :, lo:hi].contiguous()
         st = ops.block_shard_stats(t, a - lo, b - lo, heads, hidden, par).clone()
