@@ -117,6 +117,21 @@ int rst_layernorm_bwd(const float* x, const float* weight, int32_t with_bias, co
                       int32_t B, int32_t C, int64_t N,
                       void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same backward pass for callers that cannot allocate device memory or
+ * carry a workspace (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  The
+ * per-block partial sums of dweight / dbias live in a 3 MiB array inside the
+ * library, one copy per GPU the library runs on, held until the process ends;
+ * the call allocates and frees nothing.  C <= 384 (RST_ERR_INVALID beyond).
+ * All calls on one GPU share that array: calls that may overlap in time on
+ * one GPU (different streams) race -- serialise them.  The first call on a
+ * device looks the array's address up (hipGetSymbolAddress): make that call
+ * before starting a stream capture.  Results are identical to
+ * rst_layernorm_bwd. */
+int rst_layernorm_bwd_noalloc(const float* x, const float* weight, int32_t with_bias, const float* dy,
+                              float* dx, int32_t accumulate_dx, float* dweight, float* dbias,
+                              int32_t B, int32_t C, int64_t N, void* stream);
+
 /* ------------------------------------------------------------------------- */
 /* 1x1 convolution -- replaces the nn.Conv2d(kernel_size=1) calls at          */
 /* model/Restromer.py:100,103,130(qkv),149 and reduce_chan_level{3,2} :403,408.*/

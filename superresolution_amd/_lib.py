@@ -49,6 +49,7 @@ SIGNATURES = {
     "rst_layernorm_fwd": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int64, _P]),
     "rst_layernorm_bwd_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int64]),
     "rst_layernorm_bwd": (c_int32, [_P, _P, c_int32, _P, _P, c_int32, _P, _P, c_int32, c_int32, c_int64, _P, c_size_t, _P]),
+    "rst_layernorm_bwd_noalloc": (c_int32, [_P, _P, c_int32, _P, _P, c_int32, _P, _P, c_int32, c_int32, c_int64, _P]),
     "rst_conv1x1_fwd": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int64, _P]),
     "rst_conv1x1_bwd_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int64]),
     "rst_conv1x1_bwd": (c_int32, [_P, _P, _P, _P, c_int32, _P, _P, c_int32, c_int32, c_int32, c_int64, _P, c_size_t, _P]),

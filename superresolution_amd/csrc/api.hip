@@ -720,6 +720,16 @@ int rst_layernorm_bwd(const float* x, const float* weight, int32_t with_bias, co
                                 workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
+int rst_layernorm_bwd_noalloc(const float* x, const float* weight, int32_t with_bias, const float* dy,
+                              float* dx, int32_t accumulate_dx, float* dweight, float* dbias,
+                              int32_t B, int32_t C, int64_t N, void* stream) {
+    RST_REQUIRE(x && weight && dy && dx && dweight, "layernorm_bwd_noalloc: null operand");
+    RST_REQUIRE(!with_bias || dbias, "layernorm_bwd_noalloc: with_bias set but dbias is null");
+    RST_REQUIRE(B > 0 && C > 0 && N > 0, "layernorm_bwd_noalloc: empty shape");
+    return layernorm_bwd_noalloc_launch(x, weight, with_bias, dy, accumulate_dx ? dx : nullptr, dx, dweight, dbias, B, C, N,
+                                        static_cast<hipStream_t>(stream));
+}
+
 int rst_conv1x1_fwd(const float* x, const float* weight, const float* bias, const float* residual, float* y,
                     int32_t B, int32_t Cin, int32_t Cout, int64_t N, void* stream) {
     RST_REQUIRE(x && weight && y, "conv1x1_fwd: null operand");

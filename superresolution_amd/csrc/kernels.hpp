@@ -12,6 +12,10 @@ int layernorm_bwd_launch(const float* x, const float* weight, int with_bias, con
                          const float* addend, float* dx, float* dweight, float* dbias,
                          int B, int C, int64_t N, void* ws, size_t ws_bytes, hipStream_t stream);
 // dx = addend + LN-backward(dy); addend may be null or alias dx.
+// the same with the partial sums in the library's own per-device scratch array (no workspace; C <= 384)
+int layernorm_bwd_noalloc_launch(const float* x, const float* weight, int with_bias, const float* dy,
+                                 const float* addend, float* dx, float* dweight, float* dbias,
+                                 int B, int C, int64_t N, hipStream_t stream);
 
 // ---- gemm_nn.hip ----
 struct GemmNN {

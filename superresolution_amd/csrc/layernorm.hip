@@ -456,4 +456,43 @@ int layernorm_bwd_launch(const float* x, const float* weight, int with_bias, con
     return RST_OK;
 }
 
+// ---- layernorm backward for callers that cannot allocate ---------------------------------------
+// The per-block (dweight, dbias) partial sums -- the only scratch of the backward pass -- live in a
+// file-scope device array instead of a caller workspace.  Every GPU the library runs on holds its own copy
+// (3 MiB) at its own address until the process ends; the address is asked for once per device, with that
+// device current, and from then on only that pointer is used in host code (the array's name is a
+// host-side handle, not a device address).
+static __device__ __align__(256) float scratch[LN_BWD_MAX_BLOCKS * 2 * 384];
+
+static int scratch_for_current_device(float** out) {
+    static std::mutex mu;
+    static std::map<int, float*> per_device;
+    int dev = 0;
+    RST_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = per_device.find(dev);
+    if (it == per_device.end()) {
+        float* ptr = nullptr;
+        RST_HIP(hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch)));
+        RST_REQUIRE(ptr != nullptr, "layernorm_bwd_noalloc: no device address for the scratch array on device %d", dev);
+        it = per_device.emplace(dev, ptr).first;
+    }
+    *out = it->second;
+    return RST_OK;
+}
+
+int layernorm_bwd_noalloc_launch(const float* x, const float* weight, int with_bias, const float* dy,
+                                 const float* addend, float* dx, float* dweight, float* dbias,
+                                 int B, int C, int64_t N, hipStream_t stream) {
+    RST_REQUIRE(C <= 384, "layernorm_bwd_noalloc: C=%d beyond the built-in scratch (at most 384 channels)", C);
+    const size_t need = layernorm_bwd_ws_bytes(B, C, N);
+    RST_REQUIRE(need <= sizeof(float) * (size_t)LN_BWD_MAX_BLOCKS * 2 * 384,
+                "layernorm_bwd_noalloc: %zu bytes of scratch needed, %zu built in", need,
+                sizeof(float) * (size_t)LN_BWD_MAX_BLOCKS * 2 * 384);
+    float* ptr = nullptr;
+    RST_TRY(scratch_for_current_device(&ptr));
+    // every partial row that the reduction reads is written by this call's first kernel: nothing to clear
+    return layernorm_bwd_launch(x, weight, with_bias, dy, addend, dx, dweight, dbias, B, C, N, ptr, need, stream);
+}
+
 }  // namespace rst
