@@ -42,6 +42,32 @@ PEAK_HBM_GBS = 8000.0              # MI355X HBM3E peak
 MFMA_KERNELS = {"gemm_nn", "gemm_nn_ln", "gemm_nt_splitk", "pwdw", "pwdw_gate"}
 
 
+def kernel_sources_hash() -> str:
+    """sha256 over the kernel sources the library is built from: what a committed counter measurement is valid for
+    (the GPU box has no git history, so the stamp cannot be a commit id)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "superresolution_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(base, "*.hip")) + glob.glob(os.path.join(base, "*.hpp")) + [os.path.join(base, "Makefile")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_peaks():
+    """What tools/peaks.py measured on an MI355X (profiles/r*_peaks.json, newest), or None."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_peaks.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+    except (OSError, ValueError):
+        return None
+    return {k: round(v, 1) for k, v in d.items() if isinstance(v, float)} | {"file": os.path.relpath(files[-1], ROOT)}
+
+
 def build_model(seed: int = 0):
     """Default-initialised network under a fixed seed, then non-trivial LayerNorm
     scale/shift and attention temperature so those paths carry signal."""
@@ -64,7 +90,8 @@ def dist_setup(n_gpus: int):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
+        # launched by torch.distributed.run (also with one rank: the RCCL paths then run as they do with eight)
         import torch.distributed as dist
         torch.cuda.set_device(local)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
@@ -106,20 +133,26 @@ def kernel_profile(run_once):
 
 
 def measured_traffic(name, batch, size, mode, dtype="f32"):
-    """HBM bytes per launch of kernel group `name`, from the committed rocprofv3 --pmc run of this
-    same workload (profiles/r1_e_hbm_traffic.json, r1_g_bf16_hbm_traffic.json for --dtype bf16; FETCH_SIZE and
-    WRITE_SIZE collected in separate passes, FETCH_SIZE doubled as gfx950 requires).  None for any other
-    workload or kernel."""
-    path = os.path.join(ROOT, "profiles", "r1_e_hbm_traffic.json" if dtype == "f32" else "r1_g_bf16_hbm_traffic.json")
-    try:
-        d = json.load(open(path))
-    except (OSError, ValueError):
-        return None
-    c = d.get("config", {})
-    if (c.get("batch"), c.get("size"), c.get("mode")) != (batch, size, mode):
-        return None
-    k = d.get("kernels", {}).get(name)
-    return None if k is None else k.get("bytes_per_launch")
+    """HBM bytes per launch of kernel group `name` from a committed `rocprofv3 --pmc` run of this same workload
+    (profiles/*hbm_traffic*.json written by tools/summarize_pmc.py: FETCH_SIZE and WRITE_SIZE collected in separate
+    passes, FETCH_SIZE doubled as gfx950 requires).  A file counts only if it was taken with the kernel sources of
+    this tree (its `kernel_sources_sha` stamp) on this workload; otherwise None -- a stale number is worse than none."""
+    import glob
+    sha = kernel_sources_hash()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic*.json")), reverse=True):
+        if ("bf16" in os.path.basename(path)) != (dtype == "bf16"):
+            continue
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        c = d.get("config", {})
+        if d.get("kernel_sources_sha") != sha or (c.get("batch"), c.get("size"), c.get("mode")) != (batch, size, mode):
+            continue
+        k = d.get("kernels", {}).get(name)
+        if k is not None:
+            return k.get("bytes_per_launch")
+    return None
 
 
 def roofline_from(prof, traffic_of=lambda name: None):
@@ -134,6 +167,13 @@ def roofline_from(prof, traffic_of=lambda name: None):
         achieved = k["bytes"] / sec / 1e9
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": round(achieved / PEAK_HBM_GBS, 4)}
+    peaks = measured_peaks()
+    if peaks:
+        key = {"mfma": "mfma_f32_16x16x4_TFLOPs", "hbm": "copy_GBps"}[roof["bound"]]
+        if key in peaks:
+            roof["measured_peak"] = peaks[key]
+            roof["frac_of_measured_peak"] = round(achieved / peaks[key], 4)
+            roof["measured_peak_source"] = peaks["file"]
     roof.update({"kernel": name, "launches_per_step": k["launches"], "avg_launch_us": round(k["ms"] * 1e3 / k["launches"], 2),
                  "traffic": traffic_of(name), "algorithmic_bytes_per_launch": round(k["bytes"] / k["launches"])})
     total = sum(v["ms"] for v in prof.values())
@@ -201,7 +241,9 @@ def main():
         workload = f"Restormer(3,3,dim=48) {prec} inference, {B}x3x{S}x{S} per GPU"
         metric = "restormer_inference_megapixels_per_sec"
     elif args.mode in ("tiled", "frame", "frame_sharded"):
-        from superresolution_amd.parallel import sharded_frame_inference, tiled_inference
+        from superresolution_amd.parallel import Collectives, sharded_frame_inference, tiled_inference
+        import torch.distributed as dist
+        comm = Collectives(eager=dist.is_initialized())
         net.eval()
         if args.mode == "tiled":
             Hh = Ww = args.size or 2048
@@ -216,9 +258,9 @@ def main():
         def step():
             with torch.no_grad():
                 if args.mode == "tiled":
-                    return tiled_inference(net, x, tile=256, overlap=32, rank=rank, world=world, tile_batch=args.batch or 16)
+                    return tiled_inference(net, x, tile=256, overlap=32, rank=rank, world=world, tile_batch=args.batch or 16, comm=comm)
                 if args.mode == "frame_sharded":
-                    return sharded_frame_inference(net, x, rank, world, gather=True)
+                    return sharded_frame_inference(net, x, rank, world, gather=True, comm=comm)
                 return net(x)
         scaling = "weak" if args.mode == "frame" else "strong"
         pixels = Hh * Ww * (world if args.mode == "frame" else 1)
@@ -229,12 +271,13 @@ def main():
         metric = "restormer_inference_megapixels_per_sec"
         B, S = 1, Hh
     else:
-        from superresolution_amd.parallel import DataParallelTrainer
+        from superresolution_amd.parallel import Collectives, DataParallelTrainer
+        import torch.distributed as dist
         B, S = args.batch or 8, args.size or 128
         gen = torch.Generator(device=dev).manual_seed(100 + rank)
         x = torch.rand(B, 3, S, S, device=dev, generator=gen)
         tgt = torch.rand(B, 3, 2 * S, 2 * S, device=dev, generator=gen)
-        trainer = DataParallelTrainer(net, world_size=world)
+        trainer = DataParallelTrainer(net, world_size=world, comm=Collectives(eager=dist.is_initialized()))
 
         def step():
             return trainer.step(x, tgt)

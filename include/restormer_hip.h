@@ -314,6 +314,19 @@ int rst_bf16_block_fwd(const rst_block_desc* desc, const rst_block_params* param
                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* Dataset item on the GPU -- replaces LazyRAWDataset.__getitem__,             */
+/* data/loader.py:33-52 (raw / max_val, odd trailing row / column dropped) and  */
+/* downsample_raw, utils/util.py:313-321 (2 x 2 average pool), for a batch of   */
+/* sensor samples already in device memory.  raw: [B, H, W, C] interleaved,     */
+/* C <= 4, uint16 (raw_is_u16 != 0) or float32; max_val: [B] white levels       */
+/* (device).  hr: [B, C, H2, W2] with H2 = H & ~1, W2 = W & ~1; lr: [B, C,       */
+/* H2/2, W2/2].  Division and pooling run in float64 and are rounded to float32  */
+/* once, as the reference's numpy / torch calls do.                              */
+/* ------------------------------------------------------------------------- */
+int rst_raw_prepare(const void* raw, int32_t raw_is_u16, const float* max_val, float* hr, float* lr,
+                    int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* Per-kernel timing aid.  No counterpart in the reference (it has no timing   */
 /* code on this path); used by bench.py for the roofline numbers.  Between     */
 /* begin and end every kernel launch of this library is bracketed by HIP       */
@@ -323,6 +336,13 @@ int rst_bf16_block_fwd(const rst_block_desc* desc, const rst_block_params* param
 /* ------------------------------------------------------------------------- */
 int rst_profile_begin(void);
 int rst_profile_end(char* json, size_t capacity);
+
+/* Peak micro-benchmarks (no counterpart in the reference; tools/peaks.py times them):
+ * a streaming float4 copy (or, read_only != 0, a pure read) of `bytes` bytes, and bare matrix-instruction loops
+ * (kind 0: v_mfma_f32_16x16x4_f32, 1: v_mfma_f32_16x16x32_bf16, 2: v_mfma_f32_16x16x32_f16) of
+ * blocks x 4 waves x iters x 8 instructions on register operands; out holds blocks * 256 floats. */
+int rst_peak_copy(const void* src, void* dst, size_t bytes, int32_t read_only, void* stream);
+int rst_peak_mfma(int32_t kind, int32_t blocks, int32_t iters, float* out, void* stream);
 
 #ifdef __cplusplus
 }

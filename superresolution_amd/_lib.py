@@ -88,8 +88,11 @@ SIGNATURES = {
     "rst_bf16_block_prepared_bytes": (c_size_t, [_DESC]),
     "rst_bf16_block_prepare": (c_int32, [_DESC, _PAR, _P, _P]),
     "rst_bf16_block_fwd": (c_int32, [_DESC, _PAR, _P, _P, _P, _P, c_size_t, _P]),
+    "rst_raw_prepare": (c_int32, [_P, c_int32, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
     "rst_profile_begin": (c_int32, []),
     "rst_profile_end": (c_int32, [c_char_p, c_size_t]),
+    "rst_peak_copy": (c_int32, [_P, _P, c_size_t, c_int32, _P]),
+    "rst_peak_mfma": (c_int32, [c_int32, c_int32, c_int32, _P, _P]),
     "rst_block_bwd": (c_int32, [_DESC, _PAR, _P, _P, _P, _P, _GR, _P, c_size_t, _P]),
 }
 

@@ -44,9 +44,11 @@ class RawPatchDataset(Dataset):
         path = self.paths[idx]
         with np.load(path) as f:
             raw, max_val = f["raw"], float(np.asarray(f["max_val"]).reshape(-1)[0])
-        hr = to_bchw(torch.from_numpy(raw.astype(np.float32) / max_val))
+        # float64 division and pooling, rounded to float32 once: what the reference's numpy / torch calls amount to
+        # (float32 array / 0-d integer array promotes to float64; the training loop casts with .float())
+        hr = to_bchw(torch.from_numpy(raw.astype(np.float32).astype(np.float64) / max_val))
         hr = hr[:, :, : hr.shape[2] & ~1, : hr.shape[3] & ~1].contiguous()
-        return {"lr": downsample2(hr), "hr": hr, "max": max_val, "filename": os.path.basename(path)}
+        return {"lr": downsample2(hr).float(), "hr": hr.float(), "max": max_val, "filename": os.path.basename(path)}
 
 
 def collate(items: List[Dict]) -> Dict:
@@ -63,6 +65,35 @@ def loaders(train_dir: str, val_dir: str, batch_size: int, num_workers: int = 0)
     train = DataLoader(RawPatchDataset(train_dir), batch_size=batch_size, shuffle=True, num_workers=num_workers, collate_fn=collate)
     val = DataLoader(RawPatchDataset(val_dir), batch_size=1, shuffle=False, num_workers=num_workers, collate_fn=collate)
     return train, val
+
+
+def prepare_batch_gpu(raw: torch.Tensor, max_val) -> Dict[str, torch.Tensor]:
+    """The dataset item for a batch of sensor samples that already sit in GPU memory: `raw` is B x H x W x C
+    (uint16 counts or float32, C <= 4) on a ROCm device, `max_val` a number or B white levels.  Returns
+    {"hr": B x C x H2 x W2, "lr": B x C x H2/2 x W2/2} fp32, bit-identical to `RawPatchDataset` items of the same
+    samples (rst_raw_prepare: normalisation and the 2 x 2 average pool in one kernel).  No CPU fallback."""
+    from . import _lib
+    from ._lib import check
+    lib = _lib.load()
+    if not raw.is_cuda:
+        raise RuntimeError(f"prepare_batch_gpu: raw is on {raw.device}; this operator only runs on a ROCm GPU")
+    if raw.dim() == 3:
+        raw = raw.unsqueeze(0)
+    if raw.dim() != 4 or raw.shape[-1] > 4 or raw.dtype not in (torch.uint16, torch.int16, torch.float32):
+        raise RuntimeError(f"prepare_batch_gpu: expected B x H x W x C (C <= 4) uint16 or float32, got {raw.dtype} {tuple(raw.shape)}")
+    raw = raw.contiguous()
+    B, H, W, C = raw.shape
+    mv = torch.as_tensor(max_val, dtype=torch.float32).reshape(-1).to(raw.device)
+    if mv.numel() == 1:
+        mv = mv.expand(B)
+    if mv.numel() != B:
+        raise RuntimeError(f"prepare_batch_gpu: {mv.numel()} white levels for {B} samples")
+    mv = mv.contiguous()
+    hr = torch.empty((B, C, H & ~1, W & ~1), dtype=torch.float32, device=raw.device)
+    lr = torch.empty((B, C, (H & ~1) // 2, (W & ~1) // 2), dtype=torch.float32, device=raw.device)
+    check(lib.rst_raw_prepare(raw.data_ptr(), int(raw.dtype != torch.float32), mv.data_ptr(), hr.data_ptr(), lr.data_ptr(),
+                              B, H, W, C, torch.cuda.current_stream().cuda_stream), "rst_raw_prepare")
+    return {"lr": lr, "hr": hr}
 
 
 def write_synthetic_npz(out_dir: str, n: int, size: int = 64, channels: int = 4, max_val: int = 1023, seed: int = 0) -> List[str]:

@@ -123,6 +123,55 @@ def load_checkpoint(log_file: str, model: nn.Module, optimizer: Optional[torch.o
 
 
 # ----------------------------------------------------------------------------
+# model factory and the PSNR evaluation script
+# ----------------------------------------------------------------------------
+def define_model(name: str = "restormer", device: Optional[str] = None, **kwargs) -> nn.Module:
+    """Counterpart of the reference's `define_Model()` (utils/util.py:143-155) without the global `Config`:
+    "restormer" builds `Restormer(**kwargs)` -- the reference's defaults (4 channels, dim 12) when no argument is
+    given -- on `device` (the GPU when there is one, as the reference picks).  The reference's other choice,
+    "unet", is a different network that this package does not contain; as there, an unknown name gives None."""
+    if device is None:
+        device = "cuda" if torch.cuda.is_available() else "cpu"
+    if name == "restormer":
+        from .model.Restromer import Restormer
+        return Restormer(**kwargs).to(device)
+    return None
+
+
+@torch.no_grad()
+def test_psnr(model: nn.Module, val_batches: Iterable, device: Optional[str] = None, log_file: Optional[str] = None,
+              verbose: bool = True) -> Dict[str, object]:
+    """Counterpart of the reference's tests/testpsnr.py:1-74: restore the best checkpoint named by `log_file`
+    (when given), switch to eval, run every validation batch through the model and report per SAMPLE the PSNR, MSE
+    and L1 against the target, plus the mean PSNR.  The script's own PSNR has no floor: an exact match gives +inf
+    (tests/testpsnr.py:36-40).  Returns {"avg_psnr", "samples": [{"psnr", "mse", "l1"}, ...]}."""
+    if device is None:
+        device = str(next(model.parameters()).device)
+    if log_file is not None:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-6)      # as the script: only to restore its state
+        load_checkpoint(log_file, model, opt, device)
+    model.eval()
+    samples = []
+    for batch in val_batches:
+        lr, hr = _unpack(batch, device)
+        out = model(lr)
+        for i in range(out.shape[0]):
+            mse = torch.mean((out[i].float() - hr[i]) ** 2).item()
+            l1 = torch.mean((out[i].float() - hr[i]).abs()).item()
+            p = float("inf") if mse == 0 else 20.0 * math.log10(1.0 / math.sqrt(mse))
+            samples.append({"psnr": p, "mse": mse, "l1": l1})
+            if verbose:
+                print(f"Sample {len(samples)}: PSNR={p:.2f} dB, MSE={mse:.6f}, L1={l1:.6f}")
+    avg = sum(s["psnr"] for s in samples) / len(samples) if samples else float("nan")
+    if verbose:
+        print(f"Average PSNR on validation set: {avg:.2f} dB")
+    return {"avg_psnr": avg, "samples": samples}
+
+
+test_psnr.__test__ = False          # a script counterpart, not a pytest case
+
+
+# ----------------------------------------------------------------------------
 # loops
 # ----------------------------------------------------------------------------
 @torch.no_grad()

@@ -33,8 +33,14 @@ class Collectives:
     harness with other needs (several ranks on one card, where RCCL cannot run and gloo would have to stage
     device buffers itself) passes its own."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, eager: bool = False):
         self.group = group
+        # eager: issue the collectives even in a group of one rank (a single GPU then runs the very calls --
+        # bucketed asynchronous all-reduce, the attention sums' all-reduce -- that eight GPUs will run)
+        self.eager = bool(eager)
+
+    def active(self, world: int) -> bool:
+        return world > 1 or self.eager
 
     def world_size(self) -> int:
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
@@ -132,14 +138,15 @@ class DataParallelTrainer:
             for i, (p, v) in enumerate(zip(b.params, b.views)):
                 p.grad = v
                 self._owner[p] = (b, i)
-        if self.world > 1:
+        self.reduce = self.comm.active(self.world)
+        if self.reduce:
             for p in params:
                 p.register_post_accumulate_grad_hook(self._on_grad_ready)
         self.broadcast_parameters()
 
     def broadcast_parameters(self):
         """Make every rank start from rank 0's parameters."""
-        if self.world > 1:
+        if self.reduce:
             ps = list(self.model.parameters())
             with torch.no_grad():
                 flat = torch.cat([p.reshape(-1) for p in ps])         # one message instead of one per tensor
@@ -174,7 +181,7 @@ class DataParallelTrainer:
         out = self.model(x)
         loss = self.loss_fn(out, target)
         loss.backward()
-        if self.world > 1:
+        if self.reduce:
             for b in self.buckets:
                 if b.handle is None:      # a parameter without gradient this step kept the bucket open
                     b.handle = self.comm.all_reduce(b.flat, async_op=True)
@@ -219,7 +226,7 @@ def tiled_inference(model: nn.Module, image: torch.Tensor, tile: int = 256, over
     Tile t goes to rank t % world.  Each rank batches its same-shaped tiles
     (up to `tile_batch` per forward), keeps the cores of the outputs, and the
     cores are stitched into the full output on rank 0 (returned there; other
-    ranks return None).  With world == 1 no collective is used.
+    ranks return None).  With world == 1 no collective is used (unless the collectives object is `eager`).
 
     The result is the network applied per tile, which is NOT the untiled result:
     the channel attention normalises over the pixels of a tile."""
@@ -248,6 +255,12 @@ def tiled_inference(model: nn.Module, image: torch.Tensor, tile: int = 256, over
         _, _, _, _, cy0, cy1, cx0, cx1 = tiles[i]
         canvas[:, :, cy0 * scale:cy1 * scale, cx0 * scale:cx1 * scale] = core
 
+    comm = _comm(comm, process_group)
+    if comm.active(world):
+        # the number of output channels, agreed on over the ranks (a rank may hold no tile)
+        co = torch.tensor([c_out if c_out is not None else 0], device=image.device)
+        comm.all_reduce(co, op=dist.ReduceOp.MAX)
+        c_out = int(co.item())
     if world == 1:
         canvas = torch.empty((1, c_out, h * scale, w * scale), dtype=image.dtype, device=image.device)
         for i, core in results.items():
@@ -257,10 +270,6 @@ def tiled_inference(model: nn.Module, image: torch.Tensor, tile: int = 256, over
         return None
     # every rank sends its cores to rank 0 as one flat message (sizes are known from the grid)
     flat = torch.cat([results[i].reshape(-1) for i in sorted(results)]) if results else image.new_empty(0)
-    comm = _comm(comm, process_group)
-    co = torch.tensor([c_out if c_out is not None else 0], device=image.device)
-    comm.all_reduce(co, op=dist.ReduceOp.MAX)
-    c_out = int(co.item())
     sizes = []
     for r in range(world):
         n = 0
@@ -380,7 +389,7 @@ def sharded_frame_inference(model: nn.Module, image: torch.Tensor, rank: int = 0
         for blk in blocks:
             heads, hidden, par = blk.attn.num_heads, blk.ffn.hidden_features, blk._params()
             stats = ops.block_shard_stats(s.t, s.r0, s.r1, heads, hidden, par)
-            if world > 1:
+            if comm.active(world):
                 comm.all_reduce(stats)
             ops.block_shard_apply(s.t, stats, heads, hidden, par)
             _refresh_halo(s, rank, world, comm)

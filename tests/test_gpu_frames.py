@@ -1,0 +1,85 @@
+"""Whole-network parity at frame-like shapes, against the fp64 oracle and the reference-generated fixture:
+
+* the bf16 storage path against the `model_dim48_rgb` fixture (output written by the reference module itself) and
+  against the oracle on a 272 x 480 frame: PSNR against a target within 0.01 dB of the ORACLE's PSNR (the contract's
+  bf16 criterion), outputs within the bf16 tolerance;
+* the same frame in fp32 within the contract's 1e-4.  One sample, one head at full resolution and 130 560 pixels make
+  the Gram reduction split the pixels far more than 16 ways, so the slab pre-reduction in front of the softmax runs
+  (the route the 2160 x 3840 frame takes), in both precisions."""
+import math
+
+import pytest
+import torch
+
+from golden_util import check_pin, load
+from oracle import recipe
+
+pytestmark = pytest.mark.gpu
+BF16_TOL = 2e-2          # of the tensor's largest magnitude: 8 significant bits, ~6 roundings per block, 44 blocks
+FP32_TOL = 1e-4
+
+
+def _psnr(a, b):
+    mse = float(((a.double() - b.double()) ** 2).mean())
+    return 10.0 * math.log10(1.0 / mse)
+
+
+def test_bf16_network_vs_reference_fixture():
+    from superresolution_amd.model.Restromer import Restormer
+    case = recipe.MODEL_CASES[1]                      # dim48_rgb: 1 x 3 x 32 x 32
+    g = load("model_" + case[0])
+    sd, x, tgt = recipe.model_case_tensors(case, torch.float32)
+    net = Restormer(**case[1])
+    net.load_state_dict(sd, strict=True)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        out = net(x.cuda().bfloat16())
+    assert out.dtype == torch.bfloat16
+    check_pin(g, "out", out.float(), BF16_TOL, "bf16 vs reference fixture")
+    assert abs(_psnr(out.float().cpu(), tgt) - float(g["psnr"])) < 0.01
+
+
+@pytest.fixture(scope="module")
+def frame():
+    import bench
+    from oracle import restormer_oracle as orc
+    net = bench.build_model(0).cuda().eval()
+    x = torch.rand(1, 3, 272, 480, generator=torch.Generator().manual_seed(21))
+    sd64 = {k: v.detach().double().cpu() for k, v in net.state_dict().items()}
+    with torch.no_grad():
+        ref = orc.restormer_forward(x.double(), sd64)
+    g = torch.Generator().manual_seed(22)
+    target = (ref + 0.03 * torch.randn(ref.shape, generator=g, dtype=torch.float64)).clamp(0, 1)      # ~30 dB away
+    return net, x, ref, target
+
+
+def _with_profile(fn):
+    import bench
+    return bench.kernel_profile(fn)
+
+
+def test_fp32_frame_many_gram_splits_vs_oracle(frame):
+    net, x, ref, target = frame
+    out = {}
+
+    def run():
+        with torch.no_grad():
+            out["y"] = net(x.cuda())
+    prof = _with_profile(run)
+    # pre-reduction of the Gram slabs only runs when the pixels are split more than 16 ways
+    assert prof.get("reduce_slabs", {}).get("launches", 0) >= 3, sorted(prof)
+    y = out["y"].double().cpu()
+    err = float((y - ref).abs().max() / ref.abs().max())
+    assert err < FP32_TOL, err
+    assert abs(_psnr(y, target) - _psnr(ref, target)) < 1e-4
+
+
+def test_bf16_frame_many_gram_splits_vs_oracle(frame):
+    net, x, ref, target = frame
+    with torch.no_grad():
+        y = net(x.cuda().bfloat16()).double().cpu()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y_ac = net(x.cuda()).double().cpu()
+    for o in (y, y_ac):
+        assert float((o - ref).abs().max() / ref.abs().max()) < BF16_TOL
+        assert abs(_psnr(o, target) - _psnr(ref, target)) < 0.01, (_psnr(o, target), _psnr(ref, target))

@@ -8,8 +8,11 @@ Kernel groups are the names bench.py's in-library profiler uses."""
 import collections
 import csv
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 LN_FOLD_PER_PASS = 88          # two LayerNorm folds per TransformerBlock, 44 blocks
 
@@ -60,6 +63,7 @@ def passes_of(name):
 
 
 def traffic(fetch_csv, write_csv, out, workload="bench.py default (Restormer dim=48 fp32 inference, 16x3x256x256)"):
+    import bench
     f, fn = load(fetch_csv)
     w, wn = load(write_csv)
     passes = passes_of(fn)
@@ -80,6 +84,7 @@ def traffic(fetch_csv, write_csv, out, workload="bench.py default (Restormer dim
                          "FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B); KB -> bytes x1024; "
                          f"{passes:g} passes in the profiled command",
                "config": {"batch": 16, "size": 256, "mode": "infer"},
+               "kernel_sources_sha": bench.kernel_sources_hash(),
                "total_bytes_per_step": round(sum(k["fetch_bytes_per_step"] + k["write_bytes_per_step"] for k in kernels.values())),
                "kernels": kernels}, open(out, "w"), indent=1)
 
