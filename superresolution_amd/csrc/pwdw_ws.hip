@@ -8,7 +8,7 @@
 
 namespace rst {
 
-const void* pwdw_ws_gate_kernel(int ks);       // pwdw_ws_gate.hip
+const void* pwdw_ws_gate_kernel(int ks, bool f16s);       // pwdw_ws_gate.hip
 
 // ---- host side ----
 bool pwdw_ws_supported(const PwDw& a) {
@@ -32,10 +32,17 @@ int pwdw_ws_launch(const PwDw& a, hipStream_t stream) {
     const int KS = a.K / 4;
     const int NM = a.gate ? 8 : (a.K == 96 ? 6 : 3);
     const int nstrips = (int)cdiv(a.W, WS_WT), G = a.gate ? (int)cdiv(cdiv(a.hidden, 16), 4) : a.M / (16 * NM);
-    const void* kern = a.gate ? pwdw_ws_gate_kernel(KS)
-                     : KS == 24 ? reinterpret_cast<const void*>(&pwdw_ws_kernel<24, 6, false>)
+    // 96 input channels: the product runs on the f16 matrix instructions with both operands split in two (fp32
+    // accuracy, see pwdw_ws_kernel.hpp); RST_F32_MFMA=1 keeps the exact-fp32 instructions (A/B runs, inputs beyond the
+    // f16 range)
+    static const bool f32_mfma = getenv("RST_F32_MFMA") != nullptr && getenv("RST_F32_MFMA")[0] == '1';
+    const bool f16s = KS == 24 && !f32_mfma;
+    const void* kern = a.gate ? pwdw_ws_gate_kernel(KS, f16s)
+                     : KS == 24 ? (f16s ? reinterpret_cast<const void*>(&pwdw_ws_kernel<24, 6, false, true>)
+                                        : reinterpret_cast<const void*>(&pwdw_ws_kernel<24, 6, false>))
                                 : reinterpret_cast<const void*>(&pwdw_ws_kernel<12, 3, false>);
-    const size_t lds = sizeof(float) * (size_t)(WS_STAGES * ws_xch(KS) + 256 + 4 * WS_ROWF + NM * WS_T * 256 + NM * 2 * 64 + NM * KS * 64);
+    const size_t lds = sizeof(float) * (size_t)(WS_STAGES * ws_xch(KS, f16s) + 256 + 4 * WS_ROWF + NM * WS_T * 256 + NM * 2 * 64 +
+                                                (f16s ? WS_IMG_FLOATS : NM * KS * 64));
     KernelSetup su;
     RST_TRY(kernel_setup(kern, NM * 128, lds, &su));
     static std::mutex mu;
@@ -65,7 +72,7 @@ int pwdw_ws_launch(const PwDw& a, hipStream_t stream) {
     const int ncols = (int)ncols64;
     const unsigned grid = (unsigned)(cdiv(ncols64, 8) * 8 * G);
     const double N = (double)a.B * a.H * a.W;
-    ProfScope prof(stream, a.gate ? "pwdw_gate" : "pwdw", 2.0 * a.M * a.K * N + 18.0 * a.M * N,
+    ProfScope prof(stream, a.gate ? (f16s ? "pwdw_gate_f16s" : "pwdw_gate") : (f16s ? "pwdw_f16s" : "pwdw"), 2.0 * a.M * a.K * N + 18.0 * a.M * N,
                    4.0 * N * (a.K + (a.gate ? a.hidden : a.M)));
     void* args[] = {(void*)&a, (void*)&nstrips, (void*)&nsplit, (void*)&G, (void*)&ncols};
     RST_HIP(hipLaunchKernel(kern, dim3(grid), dim3(NM * 128), args, lds, stream));

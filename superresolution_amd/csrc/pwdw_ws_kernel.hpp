@@ -38,9 +38,12 @@ constexpr int WS_CPR = 20;               // 16-byte pieces per channel row in LD
 constexpr int WS_ROWF = WS_CPR * 4;      // == 16 (mod 64): the four k-rows of an operand read hit disjoint banks
 constexpr int WS_NSG = WS_ROWF / 16;     // groups of 16 ring columns for the statistics
 constexpr int WS_STAGES = 4;
-constexpr int ws_ck(int ks) { return ks >= 24 ? 48 : 24; }                    // channels per ring stage (two stages per row at least)
-constexpr int ws_ninstr(int ks) { return (ws_ck(ks) * WS_CPR + 63) / 64; }     // wave-wide DMA instructions per chunk
-constexpr int ws_xch(int ks) { return ws_ninstr(ks) * 256; }                   // floats per ring stage
+// channels per ring stage (two stages per row at least); the split-f16 form multiplies 32 channels per instruction
+constexpr int ws_ck(int ks, bool f16s = false) { return f16s ? 32 : ks >= 24 ? 48 : 24; }
+constexpr int ws_ninstr(int ks, bool f16s = false) { return (ws_ck(ks, f16s) * WS_CPR + 63) / 64; }     // wave-wide DMA instructions per chunk
+constexpr int ws_xch(int ks, bool f16s = false) { return ws_ninstr(ks, f16s) * 256; }                   // floats per ring stage
+constexpr int WS_IMG_FLOATS = 2 * 5 * 2 * 64 * 4;       // split-f16 operand image: [2 buffers][4 tiles + halo tile][hi, lo][64 lanes] x 16 B
+typedef _Float16 ws_h8 __attribute__((ext_vector_type(8)));
 
 // gelu(x) = x * Phi(x) without a branch: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 on erf, measured
 // <= 4.3e-7 absolute on gelu over [-8, 8] in fp32), one reciprocal and one exponential.  The library erff has two
@@ -66,10 +69,21 @@ __device__ __forceinline__ void ws_static_for(F&& f) {
     }
 }
 
-template <int KS, int NM, bool GATE>
+// F16S: the 1x1 product on the f16 matrix instructions at fp32 accuracy.  Both operands are split,
+// v = hi + lo / 2048 with hi = f16(v), lo = f16((v - hi) * 2048) (22 significant bits; v - hi is exact in fp32), and
+//   W x = Whi xhi + (Whi xlo + Wlo xhi) / 2048        (the lo-lo term is below fp32 rounding)
+// takes three v_mfma_f32_16x16x32_f16 (16 cycles each for 32 channels) where the fp32 form takes eight
+// v_mfma_f32_16x16x4_f32 (32 cycles each): the matrix pipe stops being the bound.  The matrix waves turn each ring
+// chunk (32 channels) into operand fragments once per block (waves 0..3 one pixel tile each, wave 4 the two halo
+// columns as a fifth tile) in a double-buffered LDS image, one phase ahead of the multiplication, so the hand-off of
+// a finished row moves from the last phase of its row to the first phase of the next and the vector waves pick it
+// up in the second.  Weights live in registers as split B operands.  |x| must stay below 65504 (f16 range).
+template <int KS, int NM, bool GATE, bool F16S = false>
 __global__ void __launch_bounds__(NM * 128) __attribute__((amdgpu_waves_per_eu(GATE ? 4 : 3, GATE ? 4 : 3)))
 pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
-    constexpr int WS_CK = ws_ck(KS), WS_NINSTR = ws_ninstr(KS), WS_XCH = ws_xch(KS);
+    constexpr int WS_CK = ws_ck(KS, F16S), WS_NINSTR = ws_ninstr(KS, F16S), WS_XCH = ws_xch(KS, F16S);
+    static_assert(!F16S || (KS % 8 == 0 && NM >= 5), "split-f16 form: whole 32-channel chunks, five converting waves");
+    constexpr int HC = F16S ? 1 : 0;                     // chunk phase in which the vector waves pick a finished row up
     constexpr int T = WS_T, WT = WS_WT, ROWF = WS_ROWF, XCH = WS_XCH;
     constexpr int ND = NM;                               // vector waves
     constexpr int PAIRS = NM / 2;                        // GATE: slab pairs per block
@@ -87,7 +101,7 @@ pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
     float* statr = statm + 2 * ROWF;                     // [2][80] 1/sqrt(var + eps)
     float* hand = statr + 2 * ROWF;                      // [NM][T][64] float4: raw 1x1 result of the last finished row
     float* halo = hand + NM * T * 256;                   // [NM][2][64]: per-lane shares of the two halo columns
-    float* wlds = halo + NM * 2 * 64;                    // [NM][KS][64] weights as MFMA B operand
+    float* wlds = halo + NM * 2 * 64;                    // [NM][KS][64] weights as MFMA B operand; F16S: the operand image instead
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -120,6 +134,89 @@ pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
 
     if (matrix) {
         // ================================ matrix wave ================================
+        if constexpr (F16S) {
+            f32x4* myhand = reinterpret_cast<f32x4*>(hand) + slab * T * 64 + lane;       // + j * 64
+            float* myhalo = halo + slab * 2 * 64 + lane;                                  // + 64: right column
+            ws_h8* img = reinterpret_cast<ws_h8*>(wlds);                                  // [2][5][2][64]
+            // lane group kk holds the channels {32 c + kk + 4 i}, i = 0..7, of chunk c -- the same set for both
+            // operands, which is all the instruction needs; with it the four groups of a fragment read four
+            // different bank quarters of the ring
+            ws_h8 whi[NC], wlo[NC];
+            {
+                const float* Ar = a.A + (int64_t)wrow * a.K;
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float w = chok ? Ar[32 * c + kk + 4 * i] : 0.f;
+                        const _Float16 h = (_Float16)w;
+                        whi[c][i] = h;
+                        wlo[c][i] = (_Float16)((w - (float)h) * 2048.f);
+                    }
+            }
+            // this wave's share of the conversion: tile `slab` (waves 0..3), the halo columns (wave 4: row 0 = the
+            // column left of the strip, row 1 = the one right of it, other rows zero)
+            const int ccol = slab < T ? 4 + 16 * slab + lm : (lm == 0 ? 3 : 4 + WT);
+            const bool cvalid = slab < T || lm < 2;
+            auto convert = [&](int stage, int buf) __attribute__((always_inline)) {
+                if (slab <= T) {
+                    const float* Xs = ring + stage * XCH + kk * ROWF + ccol;
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = Xs[4 * i * ROWF];
+                    ws_h8 hi, lo;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float x = cvalid ? v[i] : 0.f;
+                        const _Float16 h = (_Float16)x;
+                        hi[i] = h;
+                        lo[i] = (_Float16)((x - (float)h) * 2048.f);
+                    }
+                    img[((buf * 5 + slab) * 2 + 0) * 64 + lane] = hi;
+                    img[((buf * 5 + slab) * 2 + 1) * 64 + lane] = lo;
+                }
+            };
+            f32x4 acc1[T + 1], acc2[T + 1];
+#pragma unroll
+            for (int j = 0; j <= T; ++j) { acc1[j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            const int nq = nrows * NC;
+            int stage_c = 0, q = 0;
+            for (int rr = 0; rr <= nrows; ++rr) {
+                ws_static_for<0, NC>([&](auto Cc) {
+                    constexpr int c = decltype(Cc)::value;
+                    constexpr int cw = (c + NC - 1) % NC;            // chunk multiplied in this phase (converted in the previous one)
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    if (q > 0 && q <= nq) {
+                        const ws_h8* im = img + ((q - 1) & 1) * 5 * 2 * 64 + lane;
+#pragma unroll
+                        for (int j = 0; j <= T; ++j) {
+                            const ws_h8 ah = im[(j * 2 + 0) * 64], al = im[(j * 2 + 1) * 64];
+                            acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, whi[cw], acc1[j], 0, 0, 0);
+                            acc2[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wlo[cw], acc2[j], 0, 0, 0);
+                            acc2[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, whi[cw], acc2[j], 0, 0, 0);
+                        }
+                    }
+                    if (c == 0 && rr > 0) {
+                        // row rr - 1 is complete: hand it over (the vector waves read it in the next phase)
+#pragma unroll
+                        for (int j = 0; j < T; ++j) {
+                            f32x4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = fmaf(acc2[j][e], 1.0f / 2048.f, acc1[j][e]);
+                            myhand[j * 64] = o;
+                        }
+                        myhalo[0] = kk == 0 ? fmaf(acc2[T][0], 1.0f / 2048.f, acc1[T][0]) : 0.f;
+                        myhalo[64] = kk == 0 ? fmaf(acc2[T][1], 1.0f / 2048.f, acc1[T][1]) : 0.f;
+#pragma unroll
+                        for (int j = 0; j <= T; ++j) { acc1[j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                    }
+                    if (q < nq) convert(stage_c, q & 1);
+                    stage_c = stage_c == WS_STAGES - 1 ? 0 : stage_c + 1;
+                    ++q;
+                });
+            }
+            return;
+        }
         float* mywl = wlds + slab * KS * 64 + lane;
         {
             const float* Ar = a.A + (int64_t)wrow * a.K;
@@ -327,7 +424,7 @@ pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
                 }
             }
 
-            if (c == 0 && have_prev) {
+            if (c == HC && have_prev) {
                 // ---- raw row out of the hand-off buffer; LayerNorm constants, bias, zero padding ----
                 const float* sm = statm + (prow & 1) * ROWF;
                 const float* sr = statr + (prow & 1) * ROWF;
