@@ -64,6 +64,10 @@ int pwdw_launch(const PwDw& a, hipStream_t stream);
 bool pwdw_ws_supported(const PwDw& a);
 int pwdw_ws_launch(const PwDw& a, hipStream_t stream);
 
+// pwdw_f16.hip: the same operation with the product on the f16 matrix instructions (operands split in two, fp32 accuracy)
+bool pwdw_f16_supported(const PwDw& a);
+int pwdw_f16_launch(const PwDw& a, hipStream_t stream);
+
 // ---- gemm_nt.hip ----
 struct GemmNT {
     const float* A; int64_t a_s1, a_s2; int64_t lda;

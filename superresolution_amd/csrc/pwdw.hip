@@ -594,6 +594,13 @@ bool pwdw_supported(const PwDw& a) { return pwdw_plan(a).ok; }
 bool pwdw_profitable(const PwDw& a) { return pwdw_plan(a).ok; }
 
 int pwdw_launch(const PwDw& a, hipStream_t stream) {
+    // The product runs on the f16 matrix instructions with split operands (fp32 accuracy) unless RST_F32_MFMA=1.  Two
+    // forms of that: wave-specialised (pwdw_ws, 96 input channels: 685 / 503 us plain / gated at 16 x 96 x 256 x 256)
+    // and single-role (pwdw_f16: 705 / 537 us there, but ahead at 48 channels).  RST_PWDW_FORM=f / w forces one (tests).
+    static const char* form_env = getenv("RST_PWDW_FORM");
+    static const bool f32_mfma = getenv("RST_F32_MFMA") != nullptr && getenv("RST_F32_MFMA")[0] == '1';
+    const bool single = form_env != nullptr ? form_env[0] == 'f' : a.K == 48;
+    if (!f32_mfma && single && pwdw_f16_supported(a)) return pwdw_f16_launch(a, stream);
     if (pwdw_ws_supported(a)) return pwdw_ws_launch(a, stream);
     PwPlan p = pwdw_plan(a);
     RST_REQUIRE(p.ok, "pwdw: unsupported shape (K=%d W=%d)", a.K, a.W);
