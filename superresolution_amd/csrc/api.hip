@@ -65,12 +65,29 @@ struct LnIn {
     const float* beta;      // null: bias-free variant
     float* scratch;         // B*C*N floats
 };
-static size_t ln_fold_floats(int Cout, int Cin) { return (size_t)Cout * Cin + 2 * (size_t)Cout; }
+// (also holds the split-f16 operand fragments of the folded weights: rows padded to 16, columns to 32)
+static size_t ln_fold_floats(int Cout, int Cin) { return (size_t)round_up(Cout, 16) * round_up(Cin, 32) + 2 * (size_t)round_up(Cout, 16); }
+
+// Products with at least this many input channels run on the f16 matrix instructions with split operands
+// (gemm_f16s.hip: 159 -> 98 us / 151 -> 77 us for the LayerNorm-folded products at 192 / 384 channels); below it the
+// exact-fp32 kernels are HBM-bound already (96 channels at 256 x 256: 277 us against 334).  RST_F16S_MINK overrides (tests, A/B runs).
+static int f16s_min_k() {
+    static const int v = getenv("RST_F16S_MINK") != nullptr ? atoi(getenv("RST_F16S_MINK")) : 192;
+    return v;
+}
+static bool use_f16s(const GemmNN& g) { return gemm_f16s_enabled() && g.K >= f16s_min_k() && gemm_f16s_supported(g); }
 
 // y = conv1x1(LN(x)) (+bias), through the folded path when possible
 static int ln_conv1x1(const LnIn& ln, const float* w, const float* bias, int Cout, int Cin, const float* x, float* y,
                       int B, int64_t N, float* fold, hipStream_t stream) {
     GemmNN g = conv1x1_args(w, Cout, Cin, false, x, y, B, N);
+    if (use_f16s(g)) {
+        float* s = fold + (size_t)round_up(Cout, 16) * round_up(Cin, 32);
+        float* c = s + round_up(Cout, 16);
+        RST_TRY(gemm_f16s_prep_launch(w, 0, 1, Cin, 0, ln.gamma, ln.beta, bias, Cout, Cin, fold, 0, s, c, stream));
+        g.afrag = fold; g.ln_mode = ln.beta ? 1 : 2; g.ln_s = s; g.ln_c = c;
+        return gemm_nn_launch(g, stream);
+    }
     GemmNN probe = g;
     probe.A = fold;
     if (gemm_nn_ln_supported(probe)) {
@@ -139,6 +156,7 @@ struct AttnBufs {
     // scratch
     float *gram_part, *sqq_part, *sqk_part, *fold;
     float *gram_red, *sqq_red, *sqk_red;     // pre-reduced slabs when the pixel range is split more than 16 ways
+    void* mfrag;                             // split-f16 operand fragments of mfold (one matrix per sample)
     NtPlan plan;
 };
 
@@ -176,6 +194,7 @@ static void attn_carve_ws(const rst_block_desc* d, bool have_saved, Carver& cv, 
         b.gram_red = b.sqq_red = b.sqk_red = nullptr;
     }
     b.fold = cv.floats(ln_fold_floats(3 * d->C, d->C));
+    b.mfrag = cv.bytes((size_t)d->B * gemm_f16s_frag_bytes(d->C, d->C));
     if (!have_saved) {
         b.t = cv.floats((size_t)d->B * 3 * d->C * N);
         b.qkv = cv.floats((size_t)d->B * 3 * d->C * N);
@@ -292,6 +311,11 @@ static int attention_tail(const rst_block_desc* d, const rst_block_params* p, At
     g2.R = residual; g2.r_s1 = (int64_t)C * N; g2.r_s2 = 0; g2.ldr = N; g2.rscale = nullptr;
     g2.bias = d->conv_bias ? p->proj_bias : nullptr;
     g2.M = C; g2.K = C; g2.N = N; g2.nb1 = B; g2.nb2 = 1; g2.accumulate = 0;
+    if (use_f16s(g2)) {
+        const int64_t fb = (int64_t)gemm_f16s_frag_bytes(C, C);
+        RST_TRY(gemm_f16s_prep_launch(b.mfold, (int64_t)C * C, B, C, 0, nullptr, nullptr, nullptr, C, C, b.mfrag, fb, nullptr, nullptr, stream));
+        g2.afrag = b.mfrag; g2.afrag_s1 = fb; g2.afrag_s2 = 0;
+    }
     return gemm_nn_launch(g2, stream);
 }
 
@@ -421,6 +445,7 @@ static size_t ffn_ws_bytes(const rst_block_desc* d) {
     Carver cv(nullptr); FfnBufs b{};
     ffn_carve(d, false, cv, b);
     cv.floats(ln_fold_floats(2 * d->hidden, d->C));
+    cv.bytes(gemm_f16s_frag_bytes(d->C, d->hidden));
     return cv.total();
 }
 static size_t ffn_saved_bytes(const rst_block_desc* d) {
@@ -437,6 +462,7 @@ static int ffn_fwd(const rst_block_desc* d, const rst_block_params* p, const flo
     RST_REQUIRE(!d->conv_bias || (p->pin_bias && p->ffn_dw_bias && p->pout_bias), "ffn_fwd: conv_bias set but a bias is null");
     FfnBufs b{};
     float* fold = nullptr;
+    void* pfrag = nullptr;
     if (saved) {
         RST_REQUIRE(ln == nullptr, "ffn_fwd: the folded LayerNorm keeps nothing for a backward pass");
         Carver cs(saved); ffn_carve(d, true, cs, b);
@@ -445,6 +471,7 @@ static int ffn_fwd(const rst_block_desc* d, const rst_block_params* p, const flo
             return fail(RST_ERR_WORKSPACE, "ffn_fwd: workspace %zu < %zu bytes", ws_bytes, ffn_ws_bytes(d));
         Carver cw(ws); ffn_carve(d, false, cw, b);
         fold = cw.floats(ln_fold_floats(2 * d->hidden, d->C));
+        pfrag = cw.bytes(gemm_f16s_frag_bytes(d->C, d->hidden));
     }
     const int B = d->B, C = d->C, Hd = d->hidden;
     const int64_t N = (int64_t)d->H * d->W;
@@ -469,6 +496,10 @@ static int ffn_fwd(const rst_block_desc* d, const rst_block_params* p, const flo
     GemmNN g2 = conv1x1_args(p->pout_weight, C, Hd, false, b.g, y, B, N);
     g2.bias = d->conv_bias ? p->pout_bias : nullptr;
     g2.R = residual; g2.r_s1 = (int64_t)C * N; g2.r_s2 = 0; g2.ldr = N;
+    if (pfrag != nullptr && use_f16s(g2)) {
+        RST_TRY(gemm_f16s_prep_launch(p->pout_weight, 0, 1, Hd, 0, nullptr, nullptr, nullptr, C, Hd, pfrag, 0, nullptr, nullptr, stream));
+        g2.afrag = pfrag;
+    }
     return gemm_nn_launch(g2, stream);
 }
 

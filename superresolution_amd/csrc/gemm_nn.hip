@@ -215,6 +215,7 @@ int ln_fold_weights_launch(const float* w, const float* gamma, const float* beta
 int gemm_nn_launch(const GemmNN& g, hipStream_t stream) {
     RST_REQUIRE(g.M > 0 && g.K > 0 && g.N > 0 && g.nb1 > 0 && g.nb2 > 0,
                 "gemm_nn: empty problem (M=%d K=%d N=%lld batch=%dx%d)", g.M, g.K, (long long)g.N, g.nb1, g.nb2);
+    if (g.afrag != nullptr) return gemm_f16s_launch(g, stream);
     RST_REQUIRE(g.A && g.X && g.Y, "gemm_nn: null operand");
     RST_REQUIRE((int64_t)g.nb1 * g.nb2 <= 65535, "gemm_nn: batch %dx%d exceeds grid.y", g.nb1, g.nb2);
     {

@@ -35,8 +35,21 @@ struct GemmNN {
     int ln_mode;
     const float* ln_s;
     const float* ln_c;
+    // A as split-f16 operand fragments (gemm_f16s_prep_launch): when set, the product runs on the f16 matrix
+    // instructions (gemm_f16s.hip) and A / lda / transA are not read; strides between batches in bytes
+    const void* afrag; int64_t afrag_s1, afrag_s2;
 };
 int gemm_nn_launch(const GemmNN& g, hipStream_t stream);
+// gemm_f16s.hip
+size_t gemm_f16s_frag_bytes(int M, int K);
+bool gemm_f16s_enabled();                       // false under RST_F32_MFMA=1
+bool gemm_f16s_supported(const GemmNN& g);      // strides / alignment of X, Y, R
+// w: nb matrices [M][K] (row stride lda; transA: stored [K][M]) w_bs elements apart -> fragments frag_bs_bytes apart;
+// gamma (optional) scales column k; with s, c: s[m] = sum_k of the split folded row, c[m] = sum_k w[m][k] beta[k] + bias[m]
+int gemm_f16s_prep_launch(const float* w, int64_t w_bs, int nb, int lda, int transA, const float* gamma, const float* beta,
+                          const float* bias, int M, int K, void* frag, int64_t frag_bs_bytes, float* s, float* c,
+                          hipStream_t stream);
+int gemm_f16s_launch(const GemmNN& g, hipStream_t stream);
 // true when a product with ln_mode set can be served (the fused kernels need 16-byte aligned
 // operands); otherwise the caller normalises first and multiplies plainly
 bool gemm_nn_ln_supported(const GemmNN& g);
