@@ -221,8 +221,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    if args.dtype == "bf16" and args.mode not in ("infer", "frame", "tiled"):
-        raise SystemExit("--dtype bf16 is available for --mode infer, --mode frame and --mode tiled")
+    if args.dtype == "bf16" and args.mode not in ("infer", "frame", "tiled", "train"):
+        raise SystemExit("--dtype bf16 is available for --mode infer, --mode frame, --mode tiled and --mode train")
     rank, world, local = dist_setup(args.gpus)
     dev = torch.device("cuda", local)
     net = build_model(0).to(dev)
@@ -280,8 +280,12 @@ def main():
         trainer = DataParallelTrainer(net, world_size=world, comm=Collectives(eager=dist.is_initialized()))
 
         def step():
+            if args.dtype == "bf16":
+                # bf16 activations (kept per block: its bf16 input only), fp32 sums, fp32 master parameters and gradients
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    return trainer.step(x, tgt)
             return trainer.step(x, tgt)
-        workload = f"Restormer(3,3,dim=48) fp32 training step (fwd+L1+bwd+allreduce+clip+Adam), {B}x3x{S}x{S} per GPU"
+        workload = f"Restormer(3,3,dim=48) {prec} training step (fwd+L1+bwd+allreduce+clip+Adam), {B}x3x{S}x{S} per GPU"
         metric = "restormer_training_megapixels_per_sec"
 
     for _ in range(args.warmup):

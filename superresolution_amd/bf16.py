@@ -172,3 +172,86 @@ def cat(a: Packed, b: Packed) -> Packed:
     if a.C % 8:
         raise RuntimeError("cat: the first tensor's channel count must be a multiple of 8 in the packed layout")
     return Packed(torch.cat([a.data, b.data], 1), a.C + b.C)
+
+
+# ----------------------------------------------------------------------------
+# training with bf16 activations: a stage of TransformerBlocks as one autograd node
+# ----------------------------------------------------------------------------
+class _StageFn(torch.autograd.Function):
+    """A run of TransformerBlocks (one `nn.Sequential` of the network) on bf16 activations, differentiable.
+
+    Forward: the packed bf16 inference kernels (`rst_bf16_block_fwd`, fused, nothing kept but each block's INPUT in
+    packed bf16 -- 2 bytes per element and block instead of the ~26 fp32 values per element that the fp32 training
+    forward keeps).  Backward, block by block in reverse: the kept input is unpacked to fp32, the block's fp32
+    training forward is run again on it (`rst_block_fwd` with a saved buffer: activation recomputation) and
+    `rst_block_bwd` gives the input and parameter gradients in fp32.  So: bf16 storage, fp32 sums, fp32 parameters and
+    gradients; the gradient is that of the fp32 block evaluated at the bf16-rounded activations.  Inside a stage the
+    gradient between blocks stays fp32; between stages it is bf16 like the activations (what autograd does for bf16
+    tensors).  x: (B, C, H, W) bf16."""
+
+    @staticmethod
+    def forward(ctx, x, metas, caches, *flat):
+        lib = _lib.load()
+        if not x.is_cuda or x.dtype != torch.bfloat16:
+            raise RuntimeError("bf16 stage: expected a bf16 tensor on a ROCm GPU")
+        p = pack(x)
+        kept = []
+        n = len(PARAM_FIELDS)
+        for i, (heads, hidden) in enumerate(metas):
+            params = dict(zip(PARAM_FIELDS, flat[i * n:(i + 1) * n]))
+            kept.append(p.data)
+            out = Packed(torch.empty_like(p.data), p.C)
+            _block_into(lib, p, out, heads, hidden, params, caches[i])
+            p = out
+        ctx.metas, ctx.shape = metas, tuple(x.shape)
+        ctx.present = [t is not None for t in flat]
+        ctx.save_for_backward(*kept, *[t for t in flat if t is not None])
+        return unpack(p, torch.bfloat16)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import ops
+        lib = _lib.load()
+        nb = len(ctx.metas)
+        kept, rest = ctx.saved_tensors[:nb], iter(ctx.saved_tensors[nb:])
+        flat = [next(rest) if pr else None for pr in ctx.present]
+        B, C, H, W = ctx.shape
+        g = dy.float().contiguous()
+        n = len(PARAM_FIELDS)
+        grads = [None] * len(flat)
+        for i in reversed(range(nb)):
+            heads, hidden = ctx.metas[i]
+            params = dict(zip(PARAM_FIELDS, flat[i * n:(i + 1) * n]))
+            x32 = unpack(Packed(kept[i], C), torch.float32)
+            g, pg = ops.block_recompute_backward(x32, g, heads, hidden, params)
+            for j, name in enumerate(PARAM_FIELDS):
+                grads[i * n + j] = pg[name]
+        return (g.to(torch.bfloat16), None, None) + tuple(grads)
+
+
+def _block_into(lib, src: Packed, dst: Packed, heads, hidden, params, cache):
+    B, C, H, W = src.shape
+    tensors = {n: _f32(params.get(n), n) for n in PARAM_FIELDS}
+    desc = make_desc(B, C, H, W, heads, hidden, tensors["norm1_bias"] is not None, tensors["qkv_bias"] is not None)
+    nb = lib.rst_bf16_block_workspace_bytes(ctypes.byref(desc))
+    if nb == 0:
+        raise RuntimeError("bf16 block: " + lib.rst_last_error().decode("utf-8", "replace"))
+    par = _fill(BlockParams(), tensors)
+    prepared = cache.get(lib, desc, par, {n: params.get(n) for n in PARAM_FIELDS}, src.data.device) if cache is not None else None
+    ws = workspace(nb, src.data.device)
+    check(lib.rst_bf16_block_fwd(ctypes.byref(desc), ctypes.byref(par), _ptr(prepared), _ptr(src.data), _ptr(dst.data), _ptr(ws),
+                                 ws.numel(), _stream()), "rst_bf16_block_fwd")
+
+
+def stage(x: torch.Tensor, blocks) -> torch.Tensor:
+    """`blocks` (TransformerBlock modules) applied to a bf16 NCHW tensor, differentiable (see _StageFn)."""
+    metas = tuple((b.attn.num_heads, b.ffn.hidden_features) for b in blocks)
+    caches = []
+    flat = []
+    for b in blocks:
+        if getattr(b, "_pk_cache", None) is None:
+            b._pk_cache = PreparedCache()
+        caches.append(b._pk_cache)
+        par = b._params()
+        flat.extend(par[n] for n in PARAM_FIELDS)
+    return _StageFn.apply(x, metas, caches, *flat)

@@ -311,6 +311,8 @@ class Restormer(nn.Module):
                                                and torch.get_autocast_dtype("cuda") == torch.bfloat16):
             if self._bf16_inference_ok(inp_img):
                 return self._forward_bf16(inp_img)
+            if self._bf16_widths_supported(inp_img):
+                return self._forward_bf16_train(inp_img)
             # Training, or a width the packed bf16 kernels do not serve (e.g. the default dim=12): the fp32 kernels
             # on an fp32 copy of the input, result in the input's dtype -- the reference module runs under
             # autocast through ordinary torch operators, so such a call must not fail.
@@ -318,11 +320,50 @@ class Restormer(nn.Module):
                 return self._forward_fp32(inp_img.float()).to(inp_img.dtype)
         return self._forward_fp32(inp_img)
 
+    def _forward_bf16_train(self, inp_img):
+        """Differentiable forward with bf16 activations (BASELINE config 3: bf16 storage, fp32 sums, fp32 master
+        parameters and gradients).  Every stage of TransformerBlocks is one autograd node that runs the packed bf16
+        kernels forward, keeps only each block's bf16 input, and recomputes the block in fp32 for its backward
+        (`bf16.stage`); the dense 3x3 convolutions, concatenations, pixel (un)shuffles and the 1x1 reductions between
+        the stages are torch operators on bf16 NCHW tensors (their autograd); the last layer and the bilinear residual
+        run in fp32.  Returns the input's dtype."""
+        from .. import bf16 as pk
+        bf = torch.bfloat16
+        with torch.autocast("cuda", enabled=False):
+            def conv(x, c):
+                return F.conv2d(x, c.weight.to(bf), None if c.bias is None else c.bias.to(bf), padding=c.padding)
+
+            x = inp_img.to(bf)
+            e1_in = conv(x, self.patch_embed.proj)
+            e1 = pk.stage(e1_in, self.encoder_level1)
+            e2 = pk.stage(F.pixel_unshuffle(conv(e1, self.down1_2.body[0]), 2), self.encoder_level2)
+            e3 = pk.stage(F.pixel_unshuffle(conv(e2, self.down2_3.body[0]), 2), self.encoder_level3)
+            lat = pk.stage(F.pixel_unshuffle(conv(e3, self.down3_4.body[0]), 2), self.latent)
+            d3 = torch.cat([F.pixel_shuffle(conv(lat, self.up4_3.body[0]), 2), e3], 1)
+            d3 = pk.stage(conv(d3, self.reduce_chan_level3), self.decoder_level3)
+            d2 = torch.cat([F.pixel_shuffle(conv(d3, self.up3_2.body[0]), 2), e2], 1)
+            d2 = pk.stage(conv(d2, self.reduce_chan_level2), self.decoder_level2)
+            d1 = torch.cat([F.pixel_shuffle(conv(d2, self.up2_1.body[0]), 2), e1], 1)
+            d1 = pk.stage(pk.stage(d1, self.decoder_level1), self.refinement)
+            up = F.pixel_shuffle(conv(d1, self.output_upscale.body[0]), 2).float()
+            if self.dual_pixel_task:
+                out = self.output(up + conv(e1_in, self.skip_conv).float())
+            else:
+                base = F.interpolate(inp_img.float(), scale_factor=2, mode="bilinear", align_corners=False)
+                if self.output.weight.shape[0] <= 4:
+                    out = ops.conv3x3_fewout(up, self.output.weight, self.output.bias, base)
+                else:
+                    out = self.output(up) + base
+        return out.to(inp_img.dtype)
+
     def _bf16_inference_ok(self, inp_img) -> bool:
         """True when this call can run on the packed bf16 inference kernels: no autograd graph wanted, a ROCm
         tensor, and every stage's (width, heads, hidden) supported by rst_bf16_block_fwd (asked once per module)."""
         if torch.is_grad_enabled() and (inp_img.requires_grad or any(p.requires_grad for p in self.parameters())):
             return False
+        return self._bf16_widths_supported(inp_img)
+
+    def _bf16_widths_supported(self, inp_img) -> bool:
         if not inp_img.is_cuda:
             return False
         ok = getattr(self, "_bf16_widths_ok", None)

@@ -412,6 +412,31 @@ def block_forward_inplace(x, heads, hidden, params: Dict[str, Optional[torch.Ten
     return x
 
 
+def block_recompute_backward(x, dy, heads, hidden, params: Dict[str, Optional[torch.Tensor]]):
+    """Gradients of one TransformerBlock from its INPUT alone: the training forward (rst_block_fwd with a saved
+    buffer) is run again on `x`, then rst_block_bwd.  Returns (dx, {parameter name: gradient or None}); used by
+    training paths that keep only block inputs (activation recomputation)."""
+    lib = _lib.load()
+    x = _require(x, "block x")
+    dy = _require(dy, "block dy")
+    B, C, H, W = x.shape
+    tensors = {n: (None if params.get(n) is None else _require(params[n].detach(), n)) for n in PARAM_FIELDS}
+    desc = make_desc(B, C, H, W, heads, hidden, tensors["norm1_bias"] is not None, tensors["qkv_bias"] is not None)
+    par = _fill(BlockParams(), tensors)
+    saved = torch.empty(lib.rst_block_saved_bytes(ctypes.byref(desc)), dtype=torch.uint8, device=x.device)
+    nws = max(lib.rst_block_workspace_bytes(ctypes.byref(desc)), lib.rst_block_bwd_workspace_bytes(ctypes.byref(desc)))
+    ws = workspace(nws, x.device)
+    y = torch.empty_like(x)
+    check(lib.rst_block_fwd(ctypes.byref(desc), ctypes.byref(par), _ptr(x), _ptr(y), _ptr(saved), _ptr(ws), ws.numel(), _stream()),
+          "rst_block_fwd")
+    grads = {n: (None if t is None else torch.empty_like(t)) for n, t in tensors.items()}
+    gr = _fill(BlockGrads(), grads)
+    dx = torch.empty_like(x)
+    check(lib.rst_block_bwd(ctypes.byref(desc), ctypes.byref(par), _ptr(x), _ptr(dy), _ptr(saved), _ptr(dx), ctypes.byref(gr),
+                            _ptr(ws), ws.numel(), _stream()), "rst_block_bwd")
+    return dx, grads
+
+
 def _shard_args(x, heads, hidden, params):
     lib = _lib.load()
     x = _require(x, "block x")

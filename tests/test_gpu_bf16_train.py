@@ -1,0 +1,102 @@
+"""Training with bf16 activations (BASELINE config 3's precision: bf16 storage, fp32 sums, fp32 master parameters):
+gradients against the fp64 oracle / the reference-generated fixture, and a short optimiser trajectory against the
+oracle's.  Tolerances are bf16's: a block rounds its activations to 8 significant bits six times, the network has
+44 blocks; measured values are quoted next to each bound."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import load
+from oracle import recipe
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(case):
+    from superresolution_amd.model.Restromer import Restormer
+    sd, x, tgt = recipe.model_case_tensors(case, torch.float32)
+    net = Restormer(**case[1])
+    net.load_state_dict(sd, strict=True)
+    return net.cuda(), x.cuda(), tgt.cuda()
+
+
+def test_bf16_training_gradients_vs_reference_fixture():
+    """dim 48, 1 x 3 x 32 x 32: loss and every parameter gradient of the bf16-activation path against the fixture written
+    by the reference module in fp64 (norm per tensor; direction through the pinned sub-samples)."""
+    case = recipe.MODEL_CASES[1]
+    g = load("model_" + case[0])
+    net, x, tgt = _net(case)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        out = net(x)
+    assert out.dtype == torch.float32 and out.requires_grad
+    loss = (out - tgt).abs().mean()
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) <= 5e-3 * float(g["loss"])           # measured ~5e-4
+    num = den_a = den_b = 0.0
+    worst_norm = 0.0
+    for k, p in net.named_parameters():
+        assert p.grad is not None and p.grad.dtype == torch.float32 and torch.isfinite(p.grad).all(), k
+        ref = float(g["gl2/" + k])
+        got = float(p.grad.double().norm())
+        if ref > 1e-3 * float(g["grad_norm"]):                                       # tensors that carry the gradient
+            worst_norm = max(worst_norm, abs(got - ref) / ref)
+        if ("d/" + k + "/v") in g:
+            idx = recipe.subsample_index(p.grad.numel())
+            a = p.grad.detach().double().cpu().numpy().reshape(-1)[idx]
+            b = g["d/" + k + "/v"].astype(np.float64)
+            num += float((a * b).sum()); den_a += float((a * a).sum()); den_b += float((b * b).sum())
+    cos = num / math.sqrt(den_a * den_b)
+    assert cos > 0.995, cos                                                          # measured ~0.9995
+    assert worst_norm < 0.1, worst_norm
+    gn = math.sqrt(sum(float((p.grad.double() ** 2).sum()) for p in net.parameters()))
+    assert abs(gn - float(g["grad_norm"])) <= 3e-2 * float(g["grad_norm"])
+
+
+def test_bf16_training_trajectory_vs_oracle():
+    """Three steps of the reference's loop (zero_grad, forward, L1, backward, clip 1.0, Adam 1e-4 / wd 1e-6) under bf16
+    autocast follow the fp64 oracle's loss curve, and the bf16 step equals the stage-wise fp32 recomputation it is
+    defined as: the same loop on the fp32 path stays within bf16 distance."""
+    from oracle import restormer_oracle as orc
+    case = recipe.MODEL_CASES[1]
+    net, x, tgt = _net(case)
+    sd64, x64, t64 = recipe.model_case_tensors(case, torch.float64)
+    ref_losses = orc.train_steps(x64, t64, sd64, (1, 2, 4, 8), 3)[0]
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, weight_decay=1e-6)
+    losses = []
+    for _ in range(3):
+        opt.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = torch.nn.functional.l1_loss(net(x), tgt)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), max_norm=1.0)
+        opt.step()
+        losses.append(loss.item())
+    assert np.allclose(losses, [float(v) for v in ref_losses], rtol=5e-3), (losses, ref_losses)
+    assert losses[2] < losses[0]
+
+
+def test_bf16_stage_backward_is_the_fp32_block_gradient():
+    """One stage of two blocks: its input gradient equals the fp32 kernels' gradient evaluated at the bf16-rounded
+    activations (which is how the path is defined), to bf16 output rounding."""
+    from superresolution_amd import bf16
+    from superresolution_amd.model.Restromer import TransformerBlock
+    torch.manual_seed(3)
+    blocks = torch.nn.Sequential(*[TransformerBlock(96, 2, 1.25, False, "WithBias") for _ in range(2)]).cuda()
+    x = torch.randn(2, 96, 16, 24, device="cuda").bfloat16()
+    r = torch.randn(2, 96, 16, 24, device="cuda")
+    xa = x.clone().requires_grad_(True)
+    ya = bf16.stage(xa, blocks)
+    (ya.float() * r).sum().backward()
+    ga = {k: p.grad.clone() for k, p in blocks.named_parameters()}
+    for p in blocks.parameters():
+        p.grad = None
+    xb = x.float().requires_grad_(True)
+    yb = blocks(xb)
+    (yb * r).sum().backward()
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max())
+    assert rel(ya.float(), yb) < 2e-2
+    assert rel(xa.grad.float(), xb.grad) < 3e-2
+    for k, p in blocks.named_parameters():
+        assert rel(ga[k], p.grad) < 5e-2, k
