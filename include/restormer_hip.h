@@ -163,6 +163,27 @@ int rst_conv3x3_fewout_fwd(const float* x, const float* weight, const float* bia
                            int32_t B, int32_t Cin, int32_t Cout, int32_t H, int32_t W, void* stream);
 
 /* ------------------------------------------------------------------------- */
+/* Dense 3x3 convolution, zero padding 1, with the pixel (un)shuffle that      */
+/* follows it in the reference as its epilogue -- replaces                      */
+/* OverlapPatchEmbed.forward (shuffle_mode 0), model/Restromer.py:181-183;      */
+/* Downsample.forward = Conv2d(C, C/2, 3) + PixelUnshuffle(2) (mode 1),         */
+/* :188-200; Upsample.forward = Conv2d(C, 2C, 3) + PixelShuffle(2) (mode 2),    */
+/* :203-215.  x: [B, Cin, H, W]; weight: [Cout, Cin, 3, 3]; bias [Cout] or NULL. */
+/* y: mode 0 [B, Cout, H, W]; mode 1 [B, 4 Cout, H/2, W/2]; mode 2              */
+/* [B, Cout/4, 2H, 2W].  The product runs on the f16 matrix instructions with   */
+/* both operands split in two (fp32 accuracy; |x| < 65504).  Shapes:            */
+/* W a multiple of 128, or W = 32 / 64 with H a multiple of 4 / 2               */
+/* (rst_conv3x3_supported); the workspace holds the split weights.  Forward     */
+/* only (the Python mirror differentiates it with torch's convolution           */
+/* gradients).                                                                  */
+/* ------------------------------------------------------------------------- */
+size_t rst_conv3x3_workspace_bytes(int32_t Cin, int32_t Cout);
+int32_t rst_conv3x3_supported(int32_t Cin, int32_t Cout, int32_t H, int32_t W, int32_t shuffle_mode);
+int rst_conv3x3_fwd(const float* x, const float* weight, const float* bias, float* y,
+                    int32_t B, int32_t Cin, int32_t Cout, int32_t H, int32_t W, int32_t shuffle_mode,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------- */
 /* Depthwise 3x3, zero padding 1 -- replaces qkv_dwconv / dwconv,             */
 /* model/Restromer.py:87-95,116-124.  x, y: [B, C, H, W]; weight: [C, 9].     */
 /* ------------------------------------------------------------------------- */

@@ -1,0 +1,357 @@
+// Dense 3x3 convolution, zero padding 1, as an implicit GEMM on the f16 matrix instructions at fp32 accuracy, with
+// PixelUnshuffle(2) / PixelShuffle(2) as its epilogue: OverlapPatchEmbed, Downsample, Upsample of the reference
+// (model/Restromer.py:172-215) in one kernel each.
+//
+// Arithmetic as gemm_f16s.hip: both operands split in two f16 halves (22 significant bits), three
+// v_mfma_f32_16x16x32_f16 per 32 input channels and tap.  Y[co][px] = sum over (dy, ci, dx) W[co][ci][dy][dx] X[ci][px + (dy, dx)]:
+//   * the weights are split once per call into operand fragments in global memory, ordered [16-row tile][dy][32-channel
+//     chunk][dx][hi, lo] (conv3x3_f16s_prep);
+//   * a block owns 32 RT output channels x 128 pixels (TH rows x TW columns of one sample, TW = min(W, 128)).  Per
+//     (dy, channel chunk) ONE slab of the input -- 32 channels x 128 pixels of the rows shifted by dy, plus the four
+//     pixels either side when the image is wider than the tile -- comes in by LDS-DMA together with the weight
+//     fragments of its three horizontal taps; the three dx shifts are taken while reading the slab out of LDS
+//     (neighbouring column, halo column at the tile edge, zero outside the image), and converted on the way;
+//   * 2-deep ring: [everyone done with slab s-1] -> issue slab s+1 -> wait for slab s -> barrier -> multiply slab s.
+// Epilogue through a wave-private LDS transpose: mode 0 plain NCHW rows, mode 1 PixelUnshuffle(2)
+// (out[4 m + 2 (y & 1) + (x & 1)][y / 2][x / 2]), mode 2 PixelShuffle(2) (out[m / 4][2 y + (m % 4) / 2][2 x + m % 2]).
+#include "kernels.hpp"
+
+namespace rst {
+
+namespace {
+
+typedef __attribute__((address_space(1))) const void* c3_gptr;
+typedef __attribute__((address_space(3))) void* c3_lptr;
+typedef _Float16 c3_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 c3_h2 __attribute__((ext_vector_type(2)));
+typedef float c3_f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int C3_XPIECE = 272;                 // floats between the 2-row pieces of a slab (64 B apart: bank quarters)
+constexpr int C3_XS = 16 * C3_XPIECE + 256;    // slab + halo piece
+constexpr int C3_SCR_LD = 36;
+
+struct Conv3F {
+    const float* x; const void* afrag; const float* bias; float* y;
+    int Cin, Cout, H, W, TW, TH, kch, mblocks, mtiles, tiles_x, tiles_y, mode;
+};
+
+__global__ void __launch_bounds__(64)
+conv3x3_f16s_prep_kernel(const float* __restrict__ w, int Cout, int Cin, int kch, c3_h8* __restrict__ frag) {
+    const int lane = threadIdx.x, m = lane & 15, g = lane >> 4;
+    const int mt = blockIdx.x, q = blockIdx.y;             // q = (dyi * kch + kc) * 3 + dxi
+    const int dxi = q % 3, kc = (q / 3) % kch, dyi = q / (3 * kch);
+    const int row = 16 * mt + m;
+    c3_h8 hi, lo;
+#pragma unroll
+    for (int idx = 0; idx < 8; ++idx) {
+        const int ci = 32 * kc + 2 * g + 8 * (idx >> 1) + (idx & 1);
+        const float v = (row < Cout && ci < Cin) ? w[(((int64_t)row * Cin + ci) * 3 + dyi) * 3 + dxi] : 0.f;
+        const _Float16 h = (_Float16)v;
+        hi[idx] = h;
+        lo[idx] = (_Float16)((v - (float)h) * 2048.f);
+    }
+    c3_h8* out = frag + ((int64_t)mt * gridDim.y + q) * 2 * 64 + lane;
+    out[0] = hi;
+    out[64] = lo;
+}
+
+template <int RT>
+__global__ void __launch_bounds__(512)
+conv3x3_f16s_kernel(Conv3F a) {
+    constexpr int AS = 3 * 2 * RT * 2 * 256;              // three taps x 2 RT tiles x (hi, lo) x 1 KiB
+    constexpr int STAGE = C3_XS + AS;
+    constexpr int NP = 17 + 12 * RT, P = (NP + 7) / 8;
+    extern __shared__ __attribute__((aligned(16))) float c3_ring[];
+    float* ring = c3_ring;                                // 2 stages + 256 floats for surplus pieces
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lm = lane & 15, kk = lane >> 4;
+    const int nq = wave & 3, mh = wave >> 2;
+    const int mb = blockIdx.x % a.mblocks;
+    const int tile = blockIdx.x / a.mblocks;
+    const int b = blockIdx.y;
+    const int m0 = mb * 32 * RT;
+    const int x0 = (tile % a.tiles_x) * a.TW, y0 = (tile / a.tiles_x) * a.TH;
+    const int H = a.H, W = a.W, TW = a.TW;
+    const int64_t HW = (int64_t)H * W;
+    const float* Xb = a.x + (int64_t)b * a.Cin * HW;
+    const char* Af = static_cast<const char*>(a.afrag);
+    const int NS = 3 * a.kch, NQ = 9 * a.kch;
+
+    // ---- DMA pieces of this wave: ids wave + 8 i; [0, 16) slab pieces of two channel rows, 16 the halo piece,
+    // then 12 RT weight pieces (tap, tile, hi/lo) ----
+    int kind[P], dsto[P], chrow[P], ysrc0[P], xsrc[P];
+    int64_t aoff[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int id = wave + 8 * i;
+        kind[i] = 3; dsto[i] = -1; chrow[i] = 0; ysrc0[i] = 0; xsrc[i] = 0; aoff[i] = 0;
+        if (id < 16) {
+            kind[i] = 0;
+            chrow[i] = 2 * id + (lane >> 5);
+            const int n = (lane & 31) * 4;
+            ysrc0[i] = y0 + n / TW; xsrc[i] = x0 + n % TW;
+            dsto[i] = id * C3_XPIECE;
+        } else if (id == 16) {
+            kind[i] = 1;
+            chrow[i] = lane >> 1;
+            int col = (lane & 1) ? x0 + TW : x0 - 4;
+            col = col < 0 ? 0 : (col > W - 4 ? W - 4 : col);      // outside the image: any valid address, masked when read
+            ysrc0[i] = y0; xsrc[i] = col;
+            dsto[i] = 16 * C3_XPIECE;
+        } else if (id < NP) {
+            kind[i] = 2;
+            const int j = id - 17, hl = j & 1, t = (j >> 1) % (2 * RT), dxi = j / (4 * RT);
+            int mt = m0 / 16 + t;
+            if (mt > a.mtiles - 1) mt = a.mtiles - 1;
+            aoff[i] = (((int64_t)mt * NQ + dxi) * 2 + hl) * 1024 + lane * 16;
+            dsto[i] = C3_XS + ((dxi * 2 * RT + t) * 2 + hl) * 256;
+        }
+    }
+    auto issue = [&](int s) __attribute__((always_inline)) {
+        float* st = ring + (s & 1) * STAGE;
+        const int dy = s / a.kch - 1, kc = s % a.kch;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            float* dst = dsto[i] >= 0 ? st + dsto[i] : ring + 2 * STAGE;
+            const void* src;
+            if (kind[i] <= 1) {
+                int ch = 32 * kc + chrow[i];
+                if (ch > a.Cin - 1) ch = a.Cin - 1;                // channels past Cin meet zero weights
+                int ys = ysrc0[i] + dy;
+                ys = ys < 0 ? 0 : (ys > H - 1 ? H - 1 : ys);        // rows outside the image are masked when read
+                src = Xb + (int64_t)ch * HW + (int64_t)ys * W + xsrc[i];
+            } else {
+                src = Af + aoff[i] + (int64_t)s * 3 * 2048;
+            }
+            __builtin_amdgcn_global_load_lds((c3_gptr)src, (c3_lptr)dst, 16, 0, 0);
+        }
+    };
+
+    // ---- this lane's two pixels (one per 16-pixel tile) and how a horizontal tap reaches its neighbour ----
+    int a0[2][3], sJ[2][3], sE[2][3];
+    bool vx[2][3], vy[2][3];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = 32 * nq + 16 * t + lm;
+        const int ty = n / TW, tx = n % TW;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int dx = d - 1, txs = tx + dx;
+            vx[t][d] = x0 + txs >= 0 && x0 + txs < W;
+            vy[t][d] = y0 + ty + d - 1 >= 0 && y0 + ty + d - 1 < H;
+            if (txs >= 0 && txs < TW) { a0[t][d] = kk * C3_XPIECE + n + dx; sJ[t][d] = 4 * C3_XPIECE; sE[t][d] = 128; }
+            else { a0[t][d] = 16 * C3_XPIECE + kk * 16 + (txs < 0 ? 3 : 4); sJ[t][d] = 64; sE[t][d] = 8; }
+        }
+    }
+
+    f32x4 acc1[RT][2], acc2[RT][2];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (a.bias != nullptr) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + mh * 16 * RT + 16 * i + 4 * kk + r;
+                b4[r] = a.bias[m < a.Cout ? m : a.Cout - 1];
+            }
+        }
+        acc1[i][0] = b4; acc1[i][1] = b4;
+        acc2[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    issue(0);
+    for (int s = 0; s < NS; ++s) {
+        // everyone is done with slab s - 1: its stage takes slab s + 1 (past the end: the last slab again, into the
+        // stage that is not being read -- keeps the count of pieces in flight fixed); then slab s has landed
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        {
+            const int sn = s + 1 < NS ? s + 1 : NS - 1;
+            float* keep = ring;     // (issue() picks the stage by parity of its argument: force the other stage)
+            (void)keep;
+            if (s + 1 < NS) issue(sn);
+            else {
+                // same pieces, other stage
+                float* st = ring + ((s + 1) & 1) * STAGE;
+                const int dy = sn / a.kch - 1, kc = sn % a.kch;
+#pragma unroll
+                for (int i = 0; i < P; ++i) {
+                    float* dst = dsto[i] >= 0 ? st + dsto[i] : ring + 2 * STAGE;
+                    const void* src;
+                    if (kind[i] <= 1) {
+                        int ch = 32 * kc + chrow[i];
+                        if (ch > a.Cin - 1) ch = a.Cin - 1;
+                        int ys = ysrc0[i] + dy;
+                        ys = ys < 0 ? 0 : (ys > H - 1 ? H - 1 : ys);
+                        src = Xb + (int64_t)ch * HW + (int64_t)ys * W + xsrc[i];
+                    } else {
+                        src = Af + aoff[i] + (int64_t)sn * 3 * 2048;
+                    }
+                    __builtin_amdgcn_global_load_lds((c3_gptr)src, (c3_lptr)dst, 16, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(P) : "memory");
+        const float* st = ring + (s & 1) * STAGE;
+        const int dyi = s / a.kch;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            c3_h8 xh[2], xl[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const bool ok = vx[t][d] && vy[t][dyi];
+                const float* xs = st + a0[t][d];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v0 = xs[j * sJ[t][d]], v1 = xs[j * sJ[t][d] + sE[t][d]];
+                    v0 = ok ? v0 : 0.f; v1 = ok ? v1 : 0.f;
+                    const c3_f32x2 vv = {v0, v1};
+                    const c3_h2 h = __builtin_convertvector(vv, c3_h2);
+                    const c3_f32x2 sc = vv * 2048.f;
+                    const c3_f32x2 r2 = {fmaf((float)h[0], -2048.f, sc[0]), fmaf((float)h[1], -2048.f, sc[1])};
+                    const c3_h2 l = __builtin_convertvector(r2, c3_h2);
+                    xh[t][2 * j] = h[0]; xh[t][2 * j + 1] = h[1];
+                    xl[t][2 * j] = l[0]; xl[t][2 * j + 1] = l[1];
+                }
+            }
+            const c3_h8* af = reinterpret_cast<const c3_h8*>(st + C3_XS) + (d * 2 * RT + mh * RT) * 2 * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                const c3_h8 ah = af[(i * 2 + 0) * 64], al = af[(i * 2 + 1) * 64];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    acc1[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xh[t], acc1[i][t], 0, 0, 0);
+                    acc2[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, xl[t], acc2[i][t], 0, 0, 0);
+                    acc2[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, xh[t], acc2[i][t], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: the wave's 16 RT rows x 32 pixels (32 consecutive columns of ONE image row) ----
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the ring is free: reuse it
+    float* scr = ring + wave * 2 * 16 * C3_SCR_LD;
+    const int nw = 32 * nq;
+    const int yw = y0 + nw / TW, xw = x0 + nw % TW;
+    float* Yb = a.y + (int64_t)b * a.Cout * HW;          // every mode writes Cout * H * W values per sample
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        float* sl = scr + (i & 1) * 16 * C3_SCR_LD;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sl[(4 * kk + r) * C3_SCR_LD + lm] = fmaf(acc2[i][0][r], 1.0f / 2048.f, acc1[i][0][r]);
+            sl[(4 * kk + r) * C3_SCR_LD + 16 + lm] = fmaf(acc2[i][1][r], 1.0f / 2048.f, acc1[i][1][r]);
+        }
+        const int mbase = m0 + mh * 16 * RT + 16 * i;
+        if (a.mode == 0) {
+            const int rr = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int row = rr + 8 * h, m = mbase + row;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&sl[row * C3_SCR_LD + c4]);
+                if (m < a.Cout) *reinterpret_cast<f32x4*>(Yb + (int64_t)m * HW + (int64_t)yw * W + xw + c4) = v;
+            }
+        } else if (a.mode == 2) {
+            // out[m / 4][2 y + (m % 4) / 2][2 x + m % 2]: lane -> output row (c, i) = lane >> 3, 8 output columns
+            const int orow = lane >> 3, seg = lane & 7;
+            const int mrow = 4 * (orow >> 1) + 2 * (orow & 1);
+            const f32x4 e = *reinterpret_cast<const f32x4*>(&sl[mrow * C3_SCR_LD + 4 * seg]);
+            const f32x4 o = *reinterpret_cast<const f32x4*>(&sl[(mrow + 1) * C3_SCR_LD + 4 * seg]);
+            if (mbase + mrow < a.Cout) {
+                float* dst = Yb + (int64_t)((mbase + mrow) / 4) * 4 * HW + (int64_t)(2 * yw + (orow & 1)) * 2 * W + 2 * xw + 8 * seg;
+                *reinterpret_cast<f32x4*>(dst) = f32x4{e.x, o.x, e.y, o.y};
+                *reinterpret_cast<f32x4*>(dst + 4) = f32x4{e.z, o.z, e.w, o.w};
+            }
+        } else {
+            // out[4 m + 2 (y & 1) + (x & 1)][y / 2][x / 2]: lane -> row m = lane >> 2, 8 pixels -> 4 even + 4 odd columns
+            const int row = lane >> 2, part = lane & 3, m = mbase + row;
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(&sl[row * C3_SCR_LD + 8 * part]);
+            const f32x4 p1 = *reinterpret_cast<const f32x4*>(&sl[row * C3_SCR_LD + 8 * part + 4]);
+            if (m < a.Cout) {
+                float* dst = Yb + (int64_t)(4 * m + 2 * (yw & 1)) * (HW / 4) + (int64_t)(yw >> 1) * (W / 2) + ((xw + 8 * part) >> 1);
+                *reinterpret_cast<f32x4*>(dst) = f32x4{p0.x, p0.z, p1.x, p1.z};
+                *reinterpret_cast<f32x4*>(dst + HW / 4) = f32x4{p0.y, p0.w, p1.y, p1.w};
+            }
+        }
+    }
+}
+
+int c3_pick_rt(int M) {
+    int best = 1;
+    int64_t best_pad = INT64_MAX;
+    for (int rt = 4; rt >= 1; --rt) {
+        const int64_t pad = cdiv(M, 32 * rt) * 32 * rt;
+        if (pad < best_pad) { best_pad = pad; best = rt; }
+    }
+    return best;
+}
+
+}  // namespace
+
+bool conv3x3_f16s_supported(int Cin, int Cout, int H, int W, int mode) {
+    if (Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return false;
+    if (W % 32 != 0 || (W > 128 && W % 128 != 0) || (W < 128 && 128 % W != 0)) return false;
+    const int TW = W < 128 ? W : 128, TH = 128 / TW;
+    if (H % TH != 0) return false;
+    if (mode == 1 && (H % 2 != 0)) return false;
+    if (mode == 2 && Cout % 4 != 0) return false;
+    return mode >= 0 && mode <= 2;
+}
+
+size_t conv3x3_f16s_ws_bytes(int Cin, int Cout) {
+    return (size_t)round_up(Cout, 16) * 9 * (size_t)round_up(Cin, 32) * 4;
+}
+
+int conv3x3_f16s_launch(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int H, int W,
+                        int mode, void* ws, size_t ws_bytes, hipStream_t stream) {
+    RST_REQUIRE(x && w && y && B > 0 && B <= 65535, "conv3x3: bad operand");
+    RST_REQUIRE(conv3x3_f16s_supported(Cin, Cout, H, W, mode),
+                "conv3x3: unsupported shape Cin=%d Cout=%d H=%d W=%d mode=%d (W a multiple of 128, or 32 / 64 with H a multiple of 4 / 2)", Cin, Cout, H, W, mode);
+    RST_REQUIRE(aligned16(x) && aligned16(y), "conv3x3: tensors must be 16-byte aligned");
+    if (ws == nullptr || ws_bytes < conv3x3_f16s_ws_bytes(Cin, Cout) || !aligned16(ws))
+        return fail(RST_ERR_WORKSPACE, "conv3x3: workspace %zu < %zu bytes", ws_bytes, conv3x3_f16s_ws_bytes(Cin, Cout));
+    Conv3F a{};
+    a.x = x; a.afrag = ws; a.bias = bias; a.y = y;
+    a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.mode = mode;
+    a.TW = W < 128 ? W : 128; a.TH = 128 / a.TW;
+    a.kch = (int)cdiv(Cin, 32);
+    a.mtiles = (int)cdiv(Cout, 16);
+    const int rt = c3_pick_rt(Cout);
+    a.mblocks = (int)cdiv(Cout, 32 * rt);
+    a.tiles_x = W / a.TW; a.tiles_y = H / a.TH;
+    hipLaunchKernelGGL(conv3x3_f16s_prep_kernel, dim3((unsigned)a.mtiles, (unsigned)(9 * a.kch)), dim3(64), 0, stream, w, Cout, Cin,
+                       a.kch, static_cast<c3_h8*>(ws));
+    RST_LAUNCH_CHECK();
+    const int64_t gx = (int64_t)a.tiles_x * a.tiles_y * a.mblocks;
+    RST_REQUIRE(gx < (1ll << 31), "conv3x3: grid too large");
+    const size_t lds = sizeof(float) * (size_t)(2 * (C3_XS + 3 * 2 * rt * 2 * 256) + 256);
+    const void* kern = rt == 1 ? reinterpret_cast<const void*>(&conv3x3_f16s_kernel<1>)
+                     : rt == 2 ? reinterpret_cast<const void*>(&conv3x3_f16s_kernel<2>)
+                     : rt == 3 ? reinterpret_cast<const void*>(&conv3x3_f16s_kernel<3>)
+                               : reinterpret_cast<const void*>(&conv3x3_f16s_kernel<4>);
+    KernelSetup su;
+    RST_TRY(kernel_setup(kern, 512, lds, &su));
+    const double px = (double)B * H * W;
+    ProfScope prof(stream, "conv3x3_f16s", 18.0 * Cin * Cout * px, 4.0 * px * (Cin + Cout));
+    void* args[] = {(void*)&a};
+    RST_HIP(hipLaunchKernel(kern, dim3((unsigned)gx, (unsigned)B), dim3(512), args, lds, stream));
+    RST_LAUNCH_CHECK();
+    return RST_OK;
+}
+
+}  // namespace rst
+
+extern "C" {
+size_t rst_conv3x3_workspace_bytes(int32_t Cin, int32_t Cout) {
+    return (Cin > 0 && Cout > 0) ? rst::conv3x3_f16s_ws_bytes(Cin, Cout) : 0;
+}
+int32_t rst_conv3x3_supported(int32_t Cin, int32_t Cout, int32_t H, int32_t W, int32_t shuffle_mode) {
+    return rst::conv3x3_f16s_supported(Cin, Cout, H, W, shuffle_mode) ? 1 : 0;
+}
+int rst_conv3x3_fwd(const float* x, const float* weight, const float* bias, float* y, int32_t B, int32_t Cin, int32_t Cout,
+                    int32_t H, int32_t W, int32_t shuffle_mode, void* workspace, size_t workspace_bytes, void* stream) {
+    return rst::conv3x3_f16s_launch(x, weight, bias, y, B, Cin, Cout, H, W, shuffle_mode, workspace, workspace_bytes,
+                                    static_cast<hipStream_t>(stream));
+}
+}

@@ -153,7 +153,9 @@ class OverlapPatchEmbed(nn.Module):
         self.proj = nn.Conv2d(in_c, embed_dim, kernel_size=3, stride=1, padding=1, bias=bias)
 
     def forward(self, x):
-        return self.proj(x)
+        if ops.conv3x3_supported(x, self.proj.weight, 0):
+            return ops.conv3x3(x, self.proj.weight, self.proj.bias, 0)
+        return self.proj(x)            # shapes the tiled kernel does not take (W not 32 / 64 / a multiple of 128): MIOpen
 
 
 class _Permute(nn.Module):
@@ -178,6 +180,9 @@ class Downsample(nn.Module):
             _Permute(ops.pixel_unshuffle2))
 
     def forward(self, x):
+        conv = self.body[0]
+        if ops.conv3x3_supported(x, conv.weight, 1):
+            return ops.conv3x3(x, conv.weight, conv.bias, 1)        # convolution and PixelUnshuffle(2) in one kernel
         return self.body(x)
 
 
@@ -191,6 +196,9 @@ class Upsample(nn.Module):
             _Permute(ops.pixel_shuffle2))
 
     def forward(self, x):
+        conv = self.body[0]
+        if ops.conv3x3_supported(x, conv.weight, 2):
+            return ops.conv3x3(x, conv.weight, conv.bias, 2)        # convolution and PixelShuffle(2) in one kernel
         return self.body(x)
 
 

@@ -290,6 +290,59 @@ def conv3x3_fewout(x, weight, bias=None, residual=None):
 
 
 # ----------------------------------------------------------------------------
+# dense 3x3 convolution with the pixel (un)shuffle as its epilogue
+# ----------------------------------------------------------------------------
+def conv3x3_supported(x, weight, mode: int) -> bool:
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+        return False
+    B, Cin, H, W = x.shape
+    return bool(_lib.load().rst_conv3x3_supported(Cin, weight.shape[0], H, W, mode))
+
+
+class _Conv3x3Fn(torch.autograd.Function):
+    """conv2d(x, weight, bias, padding=1) followed by nothing (mode 0), nn.PixelUnshuffle(2) (mode 1) or
+    nn.PixelShuffle(2) (mode 2): reference model/Restromer.py:181-183, 188-200, 203-215.  Forward is one HIP kernel;
+    the gradients are torch's convolution gradients of the un-shuffled output gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, mode):
+        lib = _lib.load()
+        x = _require(x, "conv3x3 x")
+        w = _require(weight, "conv3x3 weight")
+        bias = _opt(bias, "conv3x3 bias")
+        B, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        if tuple(w.shape) != (Cout, Cin, 3, 3) or (bias is not None and bias.numel() != Cout):
+            raise RuntimeError(f"conv3x3: weight {tuple(w.shape)} / bias do not match {Cin} input channels")
+        shape = {0: (B, Cout, H, W), 1: (B, 4 * Cout, H // 2, W // 2), 2: (B, Cout // 4, 2 * H, 2 * W)}[mode]
+        y = torch.empty(shape, dtype=x.dtype, device=x.device)
+        ws = workspace(lib.rst_conv3x3_workspace_bytes(Cin, Cout), x.device)
+        check(lib.rst_conv3x3_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, Cin, Cout, H, W, int(mode), _ptr(ws), ws.numel(),
+                                  _stream()), "rst_conv3x3_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.mode, ctx.has_bias = mode, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = _require(dy, "conv3x3 dy")
+        if ctx.mode == 1:
+            dy = _shuffle_raw(dy)           # gradient of PixelUnshuffle is PixelShuffle
+        elif ctx.mode == 2:
+            dy = _unshuffle_raw(dy)
+        dx = torch.nn.grad.conv2d_input(x.shape, w, dy, padding=1) if ctx.needs_input_grad[0] else None
+        dw = torch.nn.grad.conv2d_weight(x, w.shape, dy, padding=1) if ctx.needs_input_grad[1] else None
+        db = dy.sum(dim=(0, 2, 3)) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db, None
+
+
+def conv3x3(x, weight, bias=None, mode: int = 0):
+    """3x3 convolution (padding 1) + nothing / PixelUnshuffle(2) / PixelShuffle(2) in one kernel."""
+    return _Conv3x3Fn.apply(x, weight, bias, mode)
+
+
+# ----------------------------------------------------------------------------
 # composite operators: MDTA, GDFN, TransformerBlock
 # ----------------------------------------------------------------------------
 ATTN_FIELDS = ("temperature", "qkv_weight", "qkv_bias", "qkv_dw_weight", "qkv_dw_bias", "proj_weight", "proj_bias")
