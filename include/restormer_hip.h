@@ -141,6 +141,15 @@ int rst_layernorm_bwd_noalloc(const float* x, const float* weight, int32_t with_
 int rst_conv1x1_fwd(const float* x, const float* weight, const float* bias, const float* residual,
                     float* y, int32_t B, int32_t Cin, int32_t Cout, int64_t N, void* stream);
 
+/* The same convolution applied to the channel concatenation of two tensors that is never written:
+ * y = W [xa; xb] (+ bias) -- replaces torch.cat([up, skip], 1) followed by reduce_chan_level{3,2},
+ * model/Restromer.py:402-403,407-408.  xa: [B, Ca, N], xb: [B, Cb, N], weight: [Cout, Ca + Cb].
+ * The workspace holds the split weights (one product over both tensors when Ca is a multiple of 32). */
+size_t rst_conv1x1_cat_workspace_bytes(int32_t Ca, int32_t Cb, int32_t Cout);
+int rst_conv1x1_cat_fwd(const float* xa, const float* xb, const float* weight, const float* bias, float* y,
+                        int32_t B, int32_t Ca, int32_t Cb, int32_t Cout, int64_t N,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* Backward: dx = W^T dy (overwritten, or accumulated when accumulate_dx != 0; may be NULL to skip),
  * dweight [Cout, Cin] = sum_b dy[b] x[b]^T, dbias [Cout] (may be NULL). */
 size_t rst_conv1x1_bwd_workspace_bytes(int32_t B, int32_t Cin, int32_t Cout, int64_t N);
@@ -161,6 +170,11 @@ int rst_conv1x1_bwd(const float* x, const float* weight, const float* dy,
 /* ------------------------------------------------------------------------- */
 int rst_conv3x3_fewout_fwd(const float* x, const float* weight, const float* bias, const float* residual, float* y,
                            int32_t B, int32_t Cin, int32_t Cout, int32_t H, int32_t W, void* stream);
+/* The same last layer with the reference's global residual computed inside: y = conv3x3(x) + bilinear x2 of the
+ * network input (F.interpolate(inp_img, scale_factor=2, mode="bilinear", align_corners=False),
+ * model/Restromer.py:420-422, added at :431).  lowres: [B, Cout, H/2, W/2]; H, W even. */
+int rst_conv3x3_fewout_up2_fwd(const float* x, const float* weight, const float* bias, const float* lowres, float* y,
+                               int32_t B, int32_t Cin, int32_t Cout, int32_t H, int32_t W, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Dense 3x3 convolution, zero padding 1, with the pixel (un)shuffle that      */

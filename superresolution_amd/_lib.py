@@ -51,6 +51,8 @@ SIGNATURES = {
     "rst_layernorm_bwd": (c_int32, [_P, _P, c_int32, _P, _P, c_int32, _P, _P, c_int32, c_int32, c_int64, _P, c_size_t, _P]),
     "rst_layernorm_bwd_noalloc": (c_int32, [_P, _P, c_int32, _P, _P, c_int32, _P, _P, c_int32, c_int32, c_int64, _P]),
     "rst_conv1x1_fwd": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int64, _P]),
+    "rst_conv1x1_cat_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "rst_conv1x1_cat_fwd": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int64, _P, c_size_t, _P]),
     "rst_conv1x1_bwd_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int64]),
     "rst_conv1x1_bwd": (c_int32, [_P, _P, _P, _P, c_int32, _P, _P, c_int32, c_int32, c_int32, c_int64, _P, c_size_t, _P]),
     "rst_dwconv3x3_fwd": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
@@ -58,6 +60,7 @@ SIGNATURES = {
     "rst_conv3x3_workspace_bytes": (c_size_t, [c_int32, c_int32]),
     "rst_conv3x3_supported": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32]),
     "rst_conv3x3_fwd": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, c_size_t, _P]),
+    "rst_conv3x3_fewout_up2_fwd": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     "rst_dwconv3x3_bwd_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
     "rst_dwconv3x3_bwd": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P, c_size_t, _P]),
     "rst_pixel_unshuffle2": (c_int32, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P]),

@@ -770,6 +770,38 @@ int rst_conv1x1_fwd(const float* x, const float* weight, const float* bias, cons
     g.R = residual; g.r_s1 = (int64_t)Cout * N; g.r_s2 = 0; g.ldr = N;
     return gemm_nn_launch(g, static_cast<hipStream_t>(stream));
 }
+size_t rst_conv1x1_cat_workspace_bytes(int32_t Ca, int32_t Cb, int32_t Cout) {
+    return (Ca > 0 && Cb > 0 && Cout > 0) ? gemm_f16s_frag_bytes(Cout, Ca + Cb) : 0;
+}
+int rst_conv1x1_cat_fwd(const float* xa, const float* xb, const float* weight, const float* bias, float* y,
+                        int32_t B, int32_t Ca, int32_t Cb, int32_t Cout, int64_t N,
+                        void* workspace, size_t workspace_bytes, void* stream) {
+    RST_REQUIRE(xa && xb && weight && y, "conv1x1_cat: null operand");
+    RST_REQUIRE(B > 0 && Ca > 0 && Cb > 0 && Cout > 0 && N > 0, "conv1x1_cat: empty shape");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int K = Ca + Cb;
+    GemmNN g = conv1x1_args(weight, Cout, K, false, xa, y, B, N);
+    g.x_s1 = (int64_t)Ca * N;
+    g.bias = bias;
+    GemmNN probe = g;
+    probe.X2 = xb;
+    if (gemm_f16s_enabled() && Ca % 32 == 0 && gemm_f16s_supported(probe) && aligned16(xb) && ((int64_t)Cb * N) % 4 == 0) {
+        // one product over both tensors: the channel chunks below Ca stream from xa, the others from xb
+        if (workspace == nullptr || workspace_bytes < rst_conv1x1_cat_workspace_bytes(Ca, Cb, Cout) || !aligned16(workspace))
+            return fail(RST_ERR_WORKSPACE, "conv1x1_cat: workspace %zu < %zu bytes", workspace_bytes, rst_conv1x1_cat_workspace_bytes(Ca, Cb, Cout));
+        RST_TRY(gemm_f16s_prep_launch(weight, 0, 1, K, 0, nullptr, nullptr, nullptr, Cout, K, workspace, 0, nullptr, nullptr, st));
+        g.afrag = workspace;
+        g.X2 = xb; g.x2_s1 = (int64_t)Cb * N; g.x2_s2 = 0; g.ksplit = Ca;
+        return gemm_nn_launch(g, st);
+    }
+    // two products into the same output: y = W[:, :Ca] xa (+bias), then y += W[:, Ca:] xb
+    g.K = Ca;                                    // lda stays Ca + Cb: the first Ca columns of every weight row
+    RST_TRY(gemm_nn_launch(g, st));
+    GemmNN h = conv1x1_args(weight + Ca, Cout, K, false, xb, y, B, N);
+    h.K = Cb; h.x_s1 = (int64_t)Cb * N; h.accumulate = 1;
+    return gemm_nn_launch(h, st);
+}
+
 size_t rst_conv1x1_bwd_workspace_bytes(int32_t B, int32_t Cin, int32_t Cout, int64_t N) {
     Carver cv(nullptr);
     cv.floats(wgrad_ws_floats(Cout, Cin, N, B));
@@ -809,6 +841,14 @@ int rst_conv3x3_fewout_fwd(const float* x, const float* weight, const float* bia
                            int32_t B, int32_t Cin, int32_t Cout, int32_t H, int32_t W, void* stream) {
     Conv3Args a{};
     a.x = x; a.w = weight; a.bias = bias; a.res = residual; a.y = y;
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
+    return conv3x3_fewout_launch(a, static_cast<hipStream_t>(stream));
+}
+int rst_conv3x3_fewout_up2_fwd(const float* x, const float* weight, const float* bias, const float* lowres, float* y,
+                               int32_t B, int32_t Cin, int32_t Cout, int32_t H, int32_t W, void* stream) {
+    RST_REQUIRE(lowres != nullptr, "conv3x3_fewout_up2: null low-resolution tensor");
+    Conv3Args a{};
+    a.x = x; a.w = weight; a.bias = bias; a.res = nullptr; a.up_src = lowres; a.y = y;
     a.B = B; a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W;
     return conv3x3_fewout_launch(a, static_cast<hipStream_t>(stream));
 }

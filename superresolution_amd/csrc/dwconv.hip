@@ -190,6 +190,31 @@ conv3x3_fewout_kernel(Conv3Args a, int strips_x, int strips_y, int64_t total) {
                     if (s.x0 + j < a.W) o[co][r][j] += a.res[off + (int64_t)yy * a.W + s.x0 + j];
             }
         }
+        if (a.up_src != nullptr) {
+            // + bilinear x2 of the low-resolution tensor (align_corners = False): source coordinate o / 2 - 1/4 clamped
+            // at 0, weights (1/4, 3/4) or (3/4, 1/4), the far index clamped at the border
+            const int h2 = a.H / 2, w2 = a.W / 2;
+            const float* lp = a.up_src + ((int64_t)b * COUT + co) * h2 * w2;
+#pragma unroll
+            for (int r = 0; r < DW_ROWS; ++r) {
+                const int yy = s.y0 + r;
+                if (yy >= a.H) continue;
+                const float sy = fmaxf(0.5f * (float)yy - 0.25f, 0.f);
+                const int iy0 = (int)sy, iy1 = iy0 + 1 < h2 ? iy0 + 1 : h2 - 1;
+                const float ly1 = sy - (float)iy0, ly0 = 1.0f - ly1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int xx = s.x0 + j;
+                    if (xx >= a.W) continue;
+                    const float sx = fmaxf(0.5f * (float)xx - 0.25f, 0.f);
+                    const int ix0 = (int)sx, ix1 = ix0 + 1 < w2 ? ix0 + 1 : w2 - 1;
+                    const float lx1 = sx - (float)ix0, lx0 = 1.0f - lx1;
+                    const float p00 = lp[(int64_t)iy0 * w2 + ix0], p01 = lp[(int64_t)iy0 * w2 + ix1];
+                    const float p10 = lp[(int64_t)iy1 * w2 + ix0], p11 = lp[(int64_t)iy1 * w2 + ix1];
+                    o[co][r][j] += ly0 * (lx0 * p00 + lx1 * p01) + ly1 * (lx0 * p10 + lx1 * p11);
+                }
+            }
+        }
         store_strip<VEC>(a.y + off, o[co], s.y0, s.x0, a.H, a.W);
     }
 }
@@ -416,6 +441,7 @@ int conv3x3_fewout_launch(const Conv3Args& a, hipStream_t stream) {
     RST_REQUIRE(a.x && a.w && a.y, "conv3x3: null operand");
     RST_REQUIRE(a.B > 0 && a.Cin > 0 && a.H > 0 && a.W > 0, "conv3x3: empty shape");
     RST_REQUIRE(a.Cout >= 1 && a.Cout <= 4, "conv3x3: this kernel serves 1..4 output channels, got %d", a.Cout);
+    RST_REQUIRE(a.up_src == nullptr || (a.H % 2 == 0 && a.W % 2 == 0), "conv3x3: the x2 residual needs even H, W");
     const int strips_x = (int)cdiv(a.W, 4), strips_y = (int)cdiv(a.H, DW_ROWS);
     const int64_t total = (int64_t)a.B * strips_x * strips_y;
     const bool vec = (a.W % 4 == 0) && aligned16(a.x) && aligned16(a.y);

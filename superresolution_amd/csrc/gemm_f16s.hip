@@ -85,6 +85,8 @@ gemm_f16s_kernel(GemmNN g, int mblocks, int mtiles, int kch) {
     const int64_t n0 = nt * GF_BN;
     const char* Af = static_cast<const char*>(g.afrag) + (int64_t)b1 * g.afrag_s1 + (int64_t)b2 * g.afrag_s2;
     const float* Xb = g.X + (int64_t)b1 * g.x_s1 + (int64_t)b2 * g.x_s2 + n0;
+    const float* X2b = g.X2 ? g.X2 + (int64_t)b1 * g.x2_s1 + (int64_t)b2 * g.x2_s2 + n0 : nullptr;
+    const int csplit = g.X2 ? g.ksplit / GF_BK : (1 << 30);       // first chunk that reads the second tensor
 
     // ---- this wave's DMA pieces: ids wave + 8 i; [0, 4 RT): A fragments (tile, hi/lo), then 16 X pieces of two rows ----
     // per piece: a lane-dependent byte offset from a wave-uniform base that advances per chunk (A: 2 KiB, X: 32 rows),
@@ -121,7 +123,8 @@ gemm_f16s_kernel(GemmNN g, int mblocks, int mtiles, int kch) {
     auto issue = [&](int c) __attribute__((always_inline)) {
         float* st = ring + (c % GF_STAGES) * STAGE;
         const char* abase = Af + (int64_t)c * 2048;
-        const char* xbase = reinterpret_cast<const char*>(Xb) + (int64_t)c * xstep;
+        const char* xbase = c < csplit ? reinterpret_cast<const char*>(Xb) + (int64_t)c * xstep
+                                       : reinterpret_cast<const char*>(X2b) + (int64_t)(c - csplit) * xstep;
         const bool lastc = c == kch - 1;
 #pragma unroll
         for (int i = 0; i < P; ++i) {
@@ -316,6 +319,9 @@ int gemm_f16s_prep_launch(const float* w, int64_t w_bs, int nb, int lda, int tra
 int gemm_f16s_launch(const GemmNN& g, hipStream_t stream) {
     RST_REQUIRE(g.afrag && g.X && g.Y && g.M > 0 && g.K > 0 && g.N > 0 && g.nb1 > 0 && g.nb2 > 0, "gemm_f16s: bad operand");
     RST_REQUIRE(gemm_f16s_supported(g), "gemm_f16s: unsupported strides / alignment");
+    RST_REQUIRE(g.X2 == nullptr || (g.ksplit > 0 && g.ksplit < g.K && g.ksplit % GF_BK == 0 && aligned16(g.X2) &&
+                                    g.x2_s1 % 4 == 0 && g.x2_s2 % 4 == 0 && g.ln_mode == 0),
+                "gemm_f16s: the second input tensor needs a split at a multiple of 32 channels");
     RST_REQUIRE(g.ln_mode == 0 || (g.ln_s && g.ln_c && g.R == nullptr && !g.accumulate && g.bias == nullptr),
                 "gemm_f16s: folded LayerNorm takes no residual / bias / accumulation");
     const int rt = gf_pick_rt(g.M);

@@ -38,6 +38,9 @@ struct GemmNN {
     // A as split-f16 operand fragments (gemm_f16s_prep_launch): when set, the product runs on the f16 matrix
     // instructions (gemm_f16s.hip) and A / lda / transA are not read; strides between batches in bytes
     const void* afrag; int64_t afrag_s1, afrag_s2;
+    // (fragment path only) the input channels come from TWO tensors: rows [0, ksplit) from X, rows [ksplit, K) from X2
+    // (same ldx; ksplit a multiple of 32): a channel concatenation that is never materialised
+    const float* X2; int64_t x2_s1, x2_s2; int ksplit;
 };
 int gemm_nn_launch(const GemmNN& g, hipStream_t stream);
 // gemm_f16s.hip
@@ -131,6 +134,7 @@ struct Conv3Args {
     const float* w;          // [Cout][Cin][3][3]
     const float* bias;       // [Cout] or null
     const float* res;        // [B][Cout][H][W] or null
+    const float* up_src;     // [B][Cout][H/2][W/2] or null: its bilinear x2 (align_corners = False) is added to the result
     float* y;                // [B][Cout][H][W]
     int B, Cin, Cout, H, W;
 };

@@ -398,10 +398,9 @@ class Restormer(nn.Module):
         e3 = self.encoder_level3(self.down2_3(e2))
         lat = self.latent(self.down3_4(e3))
 
-        d3 = torch.cat([self.up4_3(lat), e3], 1)
-        d3 = self.decoder_level3(ops.conv1x1(d3, self.reduce_chan_level3.weight, self.reduce_chan_level3.bias))
-        d2 = torch.cat([self.up3_2(d3), e2], 1)
-        d2 = self.decoder_level2(ops.conv1x1(d2, self.reduce_chan_level2.weight, self.reduce_chan_level2.bias))
+        # (the concatenations in front of the 1x1 reductions are never written: the product reads both tensors)
+        d3 = self.decoder_level3(ops.conv1x1_cat(self.up4_3(lat), e3, self.reduce_chan_level3.weight, self.reduce_chan_level3.bias))
+        d2 = self.decoder_level2(ops.conv1x1_cat(self.up3_2(d3), e2, self.reduce_chan_level2.weight, self.reduce_chan_level2.bias))
         d1 = torch.cat([self.up2_1(d2), e1], 1)
         d1 = self.refinement(self.decoder_level1(d1))
         up = self.output_upscale(d1)
@@ -409,8 +408,10 @@ class Restormer(nn.Module):
         if self.dual_pixel_task:
             # as written in the reference (model/Restromer.py:426-428)
             return self.output(up + ops.conv1x1(e1_in, self.skip_conv.weight, self.skip_conv.bias))
+        if self.output.weight.shape[0] <= 4 and self.output.weight.shape[0] == inp_img.shape[1] and not inp_img.requires_grad:
+            # last layer, bilinear x2 of the input and the residual add in one HIP kernel
+            return ops.conv3x3_fewout_up2(up, self.output.weight, self.output.bias, inp_img)
         base = F.interpolate(inp_img, scale_factor=2, mode="bilinear", align_corners=False)
         if self.output.weight.shape[0] <= 4:
-            # last layer and the residual in one HIP kernel
             return ops.conv3x3_fewout(up, self.output.weight, self.output.bias, base)
         return self.output(up) + base

@@ -150,6 +150,51 @@ def conv1x1(x, weight, bias=None):
     return _Conv1x1Fn.apply(x, weight, bias)
 
 
+class _Conv1x1CatFn(torch.autograd.Function):
+    """conv1x1(torch.cat([a, b], 1), weight, bias) without the concatenated tensor (reference: model/Restromer.py:402-403,
+    407-408).  The backward pass goes through rst_conv1x1_bwd on the concatenation (built there only)."""
+
+    @staticmethod
+    def forward(ctx, a, b, weight, bias):
+        lib = _lib.load()
+        a, b = _require(a, "conv1x1_cat a"), _require(b, "conv1x1_cat b")
+        w = _require(weight, "conv1x1_cat weight")
+        bias = _opt(bias, "conv1x1_cat bias")
+        B, Ca, H, W = a.shape
+        Cb, Cout = b.shape[1], w.shape[0]
+        if tuple(b.shape) != (B, Cb, H, W) or w.numel() != Cout * (Ca + Cb) or (bias is not None and bias.numel() != Cout):
+            raise RuntimeError(f"conv1x1_cat: shapes {tuple(a.shape)}, {tuple(b.shape)}, weight {tuple(w.shape)} do not fit")
+        y = torch.empty((B, Cout, H, W), dtype=a.dtype, device=a.device)
+        ws = workspace(lib.rst_conv1x1_cat_workspace_bytes(Ca, Cb, Cout), a.device)
+        check(lib.rst_conv1x1_cat_fwd(_ptr(a), _ptr(b), _ptr(w), _ptr(bias), _ptr(y), B, Ca, Cb, Cout, H * W, _ptr(ws), ws.numel(),
+                                      _stream()), "rst_conv1x1_cat_fwd")
+        ctx.save_for_backward(a, b, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        a, b, w = ctx.saved_tensors
+        dy = _require(dy, "conv1x1_cat dy")
+        x = torch.cat([a, b], 1)
+        B, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(w)
+        db = torch.empty(Cout, dtype=x.dtype, device=x.device) if ctx.has_bias else None
+        nb = lib.rst_conv1x1_bwd_workspace_bytes(B, Cin, Cout, H * W)
+        ws = workspace(nb, x.device)
+        check(lib.rst_conv1x1_bwd(_ptr(x), _ptr(w), _ptr(dy), _ptr(dx), 0, _ptr(dw), _ptr(db), B, Cin, Cout, H * W,
+                                  _ptr(ws), ws.numel(), _stream()), "rst_conv1x1_bwd")
+        return dx[:, :a.shape[1]].contiguous(), dx[:, a.shape[1]:].contiguous(), dw, db
+
+
+def conv1x1_cat(a, b, weight, bias=None):
+    """1x1 convolution of the channel concatenation [a, b] that is never materialised."""
+    return _Conv1x1CatFn.apply(a, b, weight, bias)
+
+
 # ----------------------------------------------------------------------------
 # depthwise 3x3 (reference: qkv_dwconv / dwconv, model/Restromer.py:87-95,116-124)
 # ----------------------------------------------------------------------------
@@ -287,6 +332,45 @@ class _Conv3x3FewOutFn(torch.autograd.Function):
 def conv3x3_fewout(x, weight, bias=None, residual=None):
     """3x3 convolution, padding 1, at most 4 output channels, optional residual add."""
     return _Conv3x3FewOutFn.apply(x, weight, bias, residual)
+
+
+class _Conv3x3FewOutUpFn(torch.autograd.Function):
+    """y = conv2d(x, weight, bias, padding=1) + bilinear x2 of `lowres` (reference: `self.output(...) + inp_img` with
+    inp_img = F.interpolate(inp_img, scale_factor=2, mode="bilinear", align_corners=False), model/Restromer.py:420-431):
+    the residual is computed inside the kernel from the low-resolution input, never materialised.  `lowres` gets no
+    gradient (it is the network's input)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, lowres):
+        lib = _lib.load()
+        x = _require(x, "conv3x3 x")
+        w = _require(weight, "conv3x3 weight")
+        bias = _opt(bias, "conv3x3 bias")
+        low = _require(lowres, "conv3x3 low-resolution residual")
+        B, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        if tuple(w.shape) != (Cout, Cin, 3, 3) or tuple(low.shape) != (B, Cout, H // 2, W // 2) or H % 2 or W % 2:
+            raise RuntimeError(f"conv3x3: weight {tuple(w.shape)} / low-resolution tensor {tuple(low.shape)} do not match x {tuple(x.shape)}")
+        y = torch.empty((B, Cout, H, W), dtype=x.dtype, device=x.device)
+        check(lib.rst_conv3x3_fewout_up2_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(low), _ptr(y), B, Cin, Cout, H, W, _stream()),
+              "rst_conv3x3_fewout_up2_fwd")
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.nn.grad.conv2d_input(x.shape, w, dy, padding=1) if ctx.needs_input_grad[0] else None
+        dw = torch.nn.grad.conv2d_weight(x, w.shape, dy, padding=1) if ctx.needs_input_grad[1] else None
+        db = dy.sum(dim=(0, 2, 3)) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db, None
+
+
+def conv3x3_fewout_up2(x, weight, bias, lowres):
+    """Last layer + bilinear x2 residual of the network input in one kernel (at most 4 output channels)."""
+    return _Conv3x3FewOutUpFn.apply(x, weight, bias, lowres)
 
 
 # ----------------------------------------------------------------------------

@@ -395,16 +395,20 @@ def sharded_frame_inference(model: nn.Module, image: torch.Tensor, rank: int = 0
             _refresh_halo(s, rank, world, comm)
         return s
 
-    def conv(s: _Slab, c: nn.Conv2d) -> torch.Tensor:
-        return F.conv2d(s.t, c.weight, c.bias, padding=1)            # rows next to a cut are wrong: cropped by the callers
+    def conv(s: _Slab, c: nn.Conv2d, mode: int = 0) -> torch.Tensor:
+        """3x3 convolution of the slab (+ PixelUnshuffle / PixelShuffle); rows next to a cut are wrong: cropped by the callers"""
+        if ops.conv3x3_supported(s.t, c.weight, mode):
+            return ops.conv3x3(s.t, c.weight, c.bias, mode)
+        y = F.conv2d(s.t, c.weight, c.bias, padding=1)
+        return y if mode == 0 else ops.pixel_unshuffle2(y) if mode == 1 else ops.pixel_shuffle2(y)
 
     def down(s: _Slab, mod, den) -> _Slab:                            # conv3x3 + PixelUnshuffle(2): rows / 2
-        y = ops.pixel_unshuffle2(conv(s, mod.body[0]))
+        y = conv(s, mod.body[0], 1)
         lo = s.lo // 2
         return slab(y[:, :, s.a // 2 - lo:s.b // 2 - lo], 1, den)
 
     def up(s: _Slab, mod, den) -> _Slab:                              # conv3x3 + PixelShuffle(2): rows * 2
-        y = ops.pixel_shuffle2(conv(s, mod.body[0]))
+        y = conv(s, mod.body[0], 2)
         lo = s.lo * 2
         return slab(y[:, :, s.a * 2 - lo:s.b * 2 - lo], 1, den)
 
@@ -417,10 +421,10 @@ def sharded_frame_inference(model: nn.Module, image: torch.Tensor, rank: int = 0
         lat = stage(model.latent, down(e3, model.down3_4, 8))
 
         d3 = up(lat, model.up4_3, 4)
-        d3.t = ops.conv1x1(torch.cat([d3.t, e3.t], 1), model.reduce_chan_level3.weight, model.reduce_chan_level3.bias)
+        d3.t = ops.conv1x1_cat(d3.t, e3.t, model.reduce_chan_level3.weight, model.reduce_chan_level3.bias)
         d3 = stage(model.decoder_level3, d3)
         d2 = up(d3, model.up3_2, 2)
-        d2.t = ops.conv1x1(torch.cat([d2.t, e2.t], 1), model.reduce_chan_level2.weight, model.reduce_chan_level2.bias)
+        d2.t = ops.conv1x1_cat(d2.t, e2.t, model.reduce_chan_level2.weight, model.reduce_chan_level2.bias)
         d2 = stage(model.decoder_level2, d2)
         d1 = up(d2, model.up2_1, 1)
         d1.t = torch.cat([d1.t, e1.t], 1)
@@ -428,7 +432,7 @@ def sharded_frame_inference(model: nn.Module, image: torch.Tensor, rank: int = 0
 
         # x2 tail on the slab: the halo of d1 (2 rows = 4 output rows) covers the last 3x3 convolution and the
         # bilinear base without another exchange
-        upt = ops.pixel_shuffle2(conv(d1, model.output_upscale.body[0]))
+        upt = conv(d1, model.output_upscale.body[0], 2)
         base = F.interpolate(x0.t, scale_factor=2, mode="bilinear", align_corners=False)
         if model.output.weight.shape[0] <= 4:
             out = ops.conv3x3_fewout(upt, model.output.weight, model.output.bias, base)
