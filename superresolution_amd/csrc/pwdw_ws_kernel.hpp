@@ -78,6 +78,13 @@ __device__ __forceinline__ void ws_static_for(F&& f) {
 // columns as a fifth tile) in a double-buffered LDS image, one phase ahead of the multiplication, so the hand-off of
 // a finished row moves from the last phase of its row to the first phase of the next and the vector waves pick it
 // up in the second.  Weights live in registers as split B operands.  |x| must stay below 65504 (f16 range).
+// In this form the matrix waves also own the block's DMA stream and the LayerNorm statistics (the sums over the
+// channels fall out of the conversion), so the vector waves carry the depthwise phase only.
+// Ablations at 16 x 96 x 256 x 256 (plain / gated, us): full kernel 679 / 496; DMA stream and barriers alone 238 / 170
+// (the input strip is read once per channel group, 3x / 2x: 1.2 GB at ~5 TB/s); matrix side without the vector
+// waves' work 507 / 355; vector side without conversion and MFMAs 591 / 350; without stores 579 / 487: neither
+// side nor memory is the single bound -- three barrier-separated phases per row of dependent LDS round trips on
+// twelve waves are.
 template <int KS, int NM, bool GATE, bool F16S = false>
 __global__ void __launch_bounds__(NM * 128) __attribute__((amdgpu_waves_per_eu(GATE ? 4 : 3, GATE ? 4 : 3)))
 pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
@@ -158,6 +165,7 @@ pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
             // column left of the strip, row 1 = the one right of it, other rows zero)
             const int ccol = slab < T ? 4 + 16 * slab + lm : (lm == 0 ? 3 : 4 + WT);
             const bool cvalid = slab < T || lm < 2;
+            float cs1 = 0.f, cs2 = 0.f;                  // LayerNorm sums of this lane's pixel column over its channel share
             auto convert = [&](int stage, int buf) __attribute__((always_inline)) {
                 if (slab <= T) {
                     const float* Xs = ring + stage * XCH + kk * ROWF + ccol;
@@ -171,21 +179,66 @@ pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
                         const _Float16 h = (_Float16)x;
                         hi[i] = h;
                         lo[i] = (_Float16)((x - (float)h) * 2048.f);
+                        cs1 += x;
+                        cs2 = fmaf(x, x, cs2);
                     }
                     img[((buf * 5 + slab) * 2 + 0) * 64 + lane] = hi;
                     img[((buf * 5 + slab) * 2 + 1) * 64 + lane] = lo;
                 }
             };
+            // ---- the block's DMA stream (the matrix waves have the time: their MFMAs fill a tenth of a phase) ----
+            constexpr int PM = (WS_NINSTR + NM - 1) / NM;
+            const char* Xb = reinterpret_cast<const char*>(a.X + (int64_t)b * a.x_bs);
+            unsigned srcoff[PM];
+            int dsto[PM];
+#pragma unroll
+            for (int p = 0; p < PM; ++p) {
+                const int i = slab + p * NM;
+                if (i < WS_NINSTR) {
+                    const int e = 64 * i + lane;
+                    const int k = e / WS_CPR < WS_CK ? e / WS_CPR : WS_CK - 1, cc = e % WS_CPR;
+                    const int px = px0 - 4 + 4 * cc;
+                    srcoff[p] = 4u * ((unsigned)(k * HW) + ((px >= 0 && px < W) ? px : 0));
+                    dsto[p] = 256 * i;
+                } else {
+                    srcoff[p] = 0;
+                    dsto[p] = -1;
+                }
+            }
+            const int nq = nrows * NC;
+            const char* isrc = Xb + 4 * (int64_t)ra * W;
+            int ic = 0, istage = 0, ileft = nq;
+            const int64_t step_c = 4 * (int64_t)WS_CK * HW, step_r = 4 * (int64_t)W - (NC - 1) * step_c;
+            auto issue = [&]() __attribute__((always_inline)) {
+                const char* src = isrc;
+                float* sbase = ring + istage * XCH;
+#pragma unroll
+                for (int p = 0; p < PM; ++p) {
+                    float* dst = dsto[p] >= 0 ? sbase + dsto[p] : ring + WS_STAGES * XCH;
+                    __builtin_amdgcn_global_load_lds((ws_gptr)(src + srcoff[p]), (ws_lptr)dst, 16, 0, 0);
+                }
+                if (ileft > 1) {
+                    const bool wrap = ic == NC - 1;
+                    isrc += wrap ? step_r : step_c;
+                    ic = wrap ? 0 : ic + 1;
+                    istage = istage == WS_STAGES - 1 ? 0 : istage + 1;
+                    --ileft;
+                }
+            };
             f32x4 acc1[T + 1], acc2[T + 1];
 #pragma unroll
             for (int j = 0; j <= T; ++j) { acc1[j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-            const int nq = nrows * NC;
+#pragma unroll
+            for (int i = 0; i < WS_STAGES - 1; ++i) issue();
             int stage_c = 0, q = 0;
+            constexpr int NEWER_M = (WS_STAGES - 2) * PM;
             for (int rr = 0; rr <= nrows; ++rr) {
                 ws_static_for<0, NC>([&](auto Cc) {
                     constexpr int c = decltype(Cc)::value;
                     constexpr int cw = (c + NC - 1) % NC;            // chunk multiplied in this phase (converted in the previous one)
-                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                    // chunk q landed for this wave (two newer chunks may be in flight), then for everyone
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(NEWER_M) : "memory");
+                    issue();
                     if (q > 0 && q <= nq) {
                         const ws_h8* im = img + ((q - 1) & 1) * 5 * 2 * 64 + lane;
 #pragma unroll
@@ -210,11 +263,30 @@ pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
 #pragma unroll
                         for (int j = 0; j <= T; ++j) { acc1[j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
                     }
-                    if (q < nq) convert(stage_c, q & 1);
+                    if (q < nq) {
+                        convert(stage_c, q & 1);
+                        if (c == NC - 1) {
+                            // per-pixel LayerNorm constants of row ra + rr, read by the vector waves in the next row's
+                            // second phase (two barriers from here)
+                            float t1 = cs1, t2 = cs2;
+                            t1 += __shfl_xor(t1, 16); t2 += __shfl_xor(t2, 16);
+                            t1 += __shfl_xor(t1, 32); t2 += __shfl_xor(t2, 32);
+                            const float mu = t1 * (1.0f / (4 * KS));
+                            const float var = fmaxf(t2 * (1.0f / (4 * KS)) - mu * mu, 0.f);
+                            if (slab <= T && cvalid && kk == 0 && a.ln_mode != 0) {
+                                const int r = ra + rr;
+                                statm[(r & 1) * ROWF + ccol] = a.ln_mode == 1 ? -mu : 0.f;
+                                statr[(r & 1) * ROWF + ccol] = 1.0f / sqrtf(var + 1e-5f);
+                            }
+                            cs1 = 0.f; cs2 = 0.f;
+                        }
+                    }
                     stage_c = stage_c == WS_STAGES - 1 ? 0 : stage_c + 1;
                     ++q;
                 });
             }
+            // all DMA (including the re-issues past the end) must have landed before the block's LDS is released
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             return;
         }
         float* mywl = wlds + slab * KS * 64 + lane;
@@ -394,8 +466,10 @@ pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
         emit(done, prow >= 1 ? prow - 1 : 0, tv0 + jj, prow - 1 >= R0 && prow - 1 < R1);
     };
 
+    if constexpr (!F16S) {
 #pragma unroll
-    for (int i = 0; i < WS_STAGES - 1; ++i) issue();
+        for (int i = 0; i < WS_STAGES - 1; ++i) issue();
+    }
     int stage_c = 0;
 
     for (int rr = 0; rr <= nrows; ++rr) {
@@ -408,13 +482,18 @@ pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
         for (int c = 0; c < NC; ++c) {
             // chunk landed for this wave (two newer chunks may be in flight), then for everyone
             constexpr int NEWER = (WS_STAGES - 2) * P;
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(NEWER) : "memory");
-            issue();
+            if constexpr (F16S) {
+                // (the split-f16 form: the matrix waves own the DMA stream and the LayerNorm statistics)
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(NEWER) : "memory");
+                issue();
+            }
             const float* Xs = ring + stage_c * XCH;
             // this wave's ring columns for the LayerNorm statistics: read now, summed at the end of the phase
             constexpr bool SAHEAD = !GATE && KS >= 24;      // statistics columns read ahead of their use (costs NTW * CKS registers)
             float sx[NTW][SAHEAD ? CKS : 1];
-            const bool do_stats = have_row && a.ln_mode != 0;
+            const bool do_stats = !F16S && have_row && a.ln_mode != 0;
             if (SAHEAD && do_stats) {
 #pragma unroll
                 for (int jj = 0; jj < NTW; ++jj) {
@@ -504,7 +583,7 @@ pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
             stage_c = stage_c == WS_STAGES - 1 ? 0 : stage_c + 1;
         }
         // per-pixel LayerNorm constants of row r, read in the next row's first phase (behind its barrier)
-        if (have_row && a.ln_mode != 0) {
+        if (!F16S && have_row && a.ln_mode != 0) {
 #pragma unroll
             for (int jj = 0; jj < NTW; ++jj) {
                 const int sg = dwave + jj * ND;
