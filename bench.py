@@ -219,6 +219,8 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="bf16: activations stored in bf16 between kernels, fp32 sums (infer, frame and tiled modes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-runs", action="store_true",
+                    help="only the named workload: no bf16_storage side measurement (profiling runs)")
     args = ap.parse_args()
 
     if args.dtype == "bf16" and args.mode not in ("infer", "frame", "tiled", "train"):
@@ -309,7 +311,7 @@ def main():
         "config": {"workload": workload, "global_batch": world * B, "input_hw": [Hh, Ww] if args.mode in ("tiled", "frame", "frame_sharded") else [S, S], "parallelism": {"tiled": f"tiles{world}", "frame_sharded": f"rows{world}"}.get(args.mode, f"dp{world}"),
                    "weights": "default init, seed 0"},
     }
-    if args.mode == "infer" and args.dtype == "f32":
+    if args.mode == "infer" and args.dtype == "f32" and not args.no_side_runs:
         # the same workload on the bf16 storage path (bf16 activations between kernels, fp32 sums), timed the same
         # way; reported beside the fp32 line, never as `value`
         xb = x.bfloat16()

@@ -109,6 +109,26 @@ def test_unfused_pair_still_matches():
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
 
 
+@pytest.mark.parametrize("switch", [{"RST_F32_MFMA": "1"}, {"RST_PWDW_FORM": "f"}, {"RST_PWDW_FORM": "w"}, {"RST_F16S_MINK": "48"}],
+                         ids=["exact_fp32_mfma", "single_role_split_f16", "wave_specialised", "split_f16_gemm_everywhere"])
+def test_product_routes_forced(switch):
+    """The MFMA-bound products of the fp32 path run on the f16 matrix instructions with split operands by default.
+    RST_F32_MFMA=1 keeps them on the exact-fp32 instruction (the route for activations beyond the f16 range);
+    RST_PWDW_FORM=f / w forces the single-role / wave-specialised fused kernel wherever it supports the shape;
+    RST_F16S_MINK=48 sends every 1x1 product from 48 input channels through the split-f16 GEMM.  Each route must pass the
+    golden block cases (switches are read once per process: child run)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, **switch)
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_block.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "not unfused and not routes_forced", "-p", "no:cacheprovider"],
+                       env=env, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
+
+
 @pytest.mark.parametrize("case", [("one_sample_c48", 48, 1, "WithBias", False, 1, 96, 96),
                                   ("one_sample_c96h2", 96, 2, "BiasFree", True, 1, 80, 128)], ids=lambda c: c[0])
 def test_single_large_sample_many_pixel_splits(case):

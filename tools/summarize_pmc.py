@@ -2,8 +2,9 @@
 """Turn rocprofv3 --pmc counter_collection.csv files of one bench.py run into the per-kernel-group
 JSON files kept under profiles/.
 
-usage: summarize_pmc.py traffic <fetch.csv> <write.csv> <out.json> [workload description]
+usage: summarize_pmc.py traffic <fetch.csv> <write.csv> <out.json> <passes> [workload description] [dtype]
        summarize_pmc.py mfma <counters.csv> <out.json>
+`passes` = workload passes in the profiled command (warm-up + timed + bench.py's own profiling pass).
 Kernel groups are the names bench.py's in-library profiler uses."""
 import collections
 import csv
@@ -27,6 +28,12 @@ def group(name):
     k, args = m.group(1), [a.strip() for a in m.group(2).split(",")]
     if k in ("gemm_nn_res_kernel", "gemm_nn_dma_kernel"):
         return "gemm_nn_ln" if args[3] == "true" else "gemm_nn"
+    if k == "gemm_f16s_kernel":
+        return "gemm_f16s_ln" if args[2] == "true" else "gemm_f16s"
+    if k == "pwdw_f16_kernel":
+        return "pwdw_gate_f16" if args[3] == "true" else "pwdw_f16"
+    if k == "conv3x3_f16s_kernel":
+        return "conv3x3_f16s"
     if k == "gemm_pk_kernel":
         return "pk_gemm_ln" if args[2] == "true" else "pk_gemm"
     if k == "dw_pk_kernel":
@@ -38,7 +45,8 @@ def group(name):
     if k == "pwdw_kernel":
         return "pwdw_gate" if args[2] == "true" else "pwdw"
     if k == "pwdw_ws_kernel":
-        return "pwdw_gate" if args[2] == "true" else "pwdw"
+        f16s = len(args) > 3 and args[3] == "true"
+        return ("pwdw_gate" if args[2] == "true" else "pwdw") + ("_f16s" if f16s else "")
     return {"gemm_nt_kernel": "gemm_nt_splitk", "dwconv_fwd_kernel": "dwconv3x3", "dwconv_gate_fwd_kernel": "dwconv3x3_gate",
             "pixel_shuffle2_kernel": "pixel_shuffle2+pixel_unshuffle2", "conv3x3_fewout_kernel": "conv3x3_fewout",
             "gemm_nn_kernel": "gemm_nn"}.get(k, k)
@@ -62,11 +70,11 @@ def passes_of(name):
     return sum(1 for n in name.values() if "gram_pk_kernel" in n) / (LN_FOLD_PER_PASS / 2)
 
 
-def traffic(fetch_csv, write_csv, out, workload="bench.py default (Restormer dim=48 fp32 inference, 16x3x256x256)"):
+def traffic(fetch_csv, write_csv, out, passes, workload="bench.py default (Restormer dim=48 fp32 inference, 16x3x256x256)", dtype="f32"):
     import bench
     f, fn = load(fetch_csv)
     w, wn = load(write_csv)
-    passes = passes_of(fn)
+    passes = float(passes)
     agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
     for d, v in f.items():
         agg[group(fn[d])][0] += 1
@@ -80,7 +88,8 @@ def traffic(fetch_csv, write_csv, out, workload="bench.py default (Restormer dim
         kernels[g] = {"launches_per_step": lp, "fetch_bytes_per_step": round(fb), "write_bytes_per_step": round(wb),
                       "bytes_per_launch": round((fb + wb) / lp)}
     json.dump({"workload": workload,
-               "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of bench.py --steps 1 --warmup 1; "
+               "dtype": dtype,
+               "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of bench.py --steps 1 --warmup 1 --no-side-runs; "
                          "FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B); KB -> bytes x1024; "
                          f"{passes:g} passes in the profiled command",
                "config": {"batch": 16, "size": 256, "mode": "infer"},
@@ -115,6 +124,6 @@ def mfma(counters_csv, out):
 
 if __name__ == "__main__":
     if sys.argv[1] == "traffic":
-        traffic(*sys.argv[2:6])
+        traffic(*sys.argv[2:8])
     else:
         mfma(sys.argv[2], sys.argv[3])
