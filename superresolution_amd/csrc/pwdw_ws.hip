@@ -41,7 +41,7 @@ int pwdw_ws_launch(const PwDw& a, hipStream_t stream) {
                      : KS == 24 ? (f16s ? reinterpret_cast<const void*>(&pwdw_ws_kernel<24, 6, false, true>)
                                         : reinterpret_cast<const void*>(&pwdw_ws_kernel<24, 6, false>))
                                 : reinterpret_cast<const void*>(&pwdw_ws_kernel<12, 3, false>);
-    const size_t lds = sizeof(float) * (size_t)(WS_STAGES * ws_xch(KS, f16s) + 256 + 4 * WS_ROWF + NM * WS_T * 256 + NM * 2 * 64 +
+    const size_t lds = sizeof(float) * (size_t)(ws_stages(f16s) * ws_xch(KS, f16s) + 256 + 4 * WS_ROWF + NM * WS_T * 256 + NM * 2 * 64 +
                                                 (f16s ? WS_IMG_FLOATS : NM * KS * 64));
     KernelSetup su;
     RST_TRY(kernel_setup(kern, NM * 128, lds, &su));

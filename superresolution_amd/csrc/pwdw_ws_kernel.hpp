@@ -37,7 +37,9 @@ constexpr int WS_WT = 16 * WS_T;         // strip width
 constexpr int WS_CPR = 20;               // 16-byte pieces per channel row in LDS (4 px halo + 64 + 4 px halo, padded)
 constexpr int WS_ROWF = WS_CPR * 4;      // == 16 (mod 64): the four k-rows of an operand read hit disjoint banks
 constexpr int WS_NSG = WS_ROWF / 16;     // groups of 16 ring columns for the statistics
-constexpr int WS_STAGES = 4;
+constexpr int WS_STAGES_F32 = 4;
+// ring depth: the split-f16 form is short of bytes in flight, not of LDS (its weights are in registers): 8 stages
+constexpr int ws_stages(bool f16s) { return f16s ? 8 : WS_STAGES_F32; }
 // channels per ring stage (two stages per row at least); the split-f16 form multiplies 32 channels per instruction
 constexpr int ws_ck(int ks, bool f16s = false) { return f16s ? 32 : ks >= 24 ? 48 : 24; }
 constexpr int ws_ninstr(int ks, bool f16s = false) { return (ws_ck(ks, f16s) * WS_CPR + 63) / 64; }     // wave-wide DMA instructions per chunk
@@ -88,6 +90,7 @@ __device__ __forceinline__ void ws_static_for(F&& f) {
 template <int KS, int NM, bool GATE, bool F16S = false>
 __global__ void __launch_bounds__(NM * 128) __attribute__((amdgpu_waves_per_eu(GATE ? 4 : 3, GATE ? 4 : 3)))
 pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
+    constexpr int STG = ws_stages(F16S);
     constexpr int WS_CK = ws_ck(KS, F16S), WS_NINSTR = ws_ninstr(KS, F16S), WS_XCH = ws_xch(KS, F16S);
     static_assert(!F16S || (KS % 8 == 0 && NM >= 5), "split-f16 form: whole 32-channel chunks, five converting waves");
     constexpr int HC = F16S ? 1 : 0;                     // chunk phase in which the vector waves pick a finished row up
@@ -103,8 +106,8 @@ pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
     static_assert(KS % CKS == 0 && NC >= 2, "the depthwise phase is split over the first and the last chunk of a row");
     constexpr int NTW = (WS_NSG + ND - 1) / ND;          // statistics groups per vector wave
     extern __shared__ __attribute__((aligned(16))) float ws_smem[];
-    float* ring = ws_smem;                               // WS_STAGES stages + 256 floats for surplus DMA pieces
-    float* statm = ring + WS_STAGES * XCH + 256;         // [2][80] minus mean (or 0) per ring column, by row parity
+    float* ring = ws_smem;                               // STG stages + 256 floats for surplus DMA pieces
+    float* statm = ring + STG * XCH + 256;         // [2][80] minus mean (or 0) per ring column, by row parity
     float* statr = statm + 2 * ROWF;                     // [2][80] 1/sqrt(var + eps)
     float* hand = statr + 2 * ROWF;                      // [NM][T][64] float4: raw 1x1 result of the last finished row
     float* halo = hand + NM * T * 256;                   // [NM][2][64]: per-lane shares of the two halo columns
@@ -214,14 +217,14 @@ pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
                 float* sbase = ring + istage * XCH;
 #pragma unroll
                 for (int p = 0; p < PM; ++p) {
-                    float* dst = dsto[p] >= 0 ? sbase + dsto[p] : ring + WS_STAGES * XCH;
+                    float* dst = dsto[p] >= 0 ? sbase + dsto[p] : ring + STG * XCH;
                     __builtin_amdgcn_global_load_lds((ws_gptr)(src + srcoff[p]), (ws_lptr)dst, 16, 0, 0);
                 }
                 if (ileft > 1) {
                     const bool wrap = ic == NC - 1;
                     isrc += wrap ? step_r : step_c;
                     ic = wrap ? 0 : ic + 1;
-                    istage = istage == WS_STAGES - 1 ? 0 : istage + 1;
+                    istage = istage == STG - 1 ? 0 : istage + 1;
                     --ileft;
                 }
             };
@@ -229,9 +232,9 @@ pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
 #pragma unroll
             for (int j = 0; j <= T; ++j) { acc1[j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-            for (int i = 0; i < WS_STAGES - 1; ++i) issue();
+            for (int i = 0; i < STG - 1; ++i) issue();
             int stage_c = 0, q = 0;
-            constexpr int NEWER_M = (WS_STAGES - 2) * PM;
+            constexpr int NEWER_M = (STG - 2) * PM;
             for (int rr = 0; rr <= nrows; ++rr) {
                 ws_static_for<0, NC>([&](auto Cc) {
                     constexpr int c = decltype(Cc)::value;
@@ -281,7 +284,7 @@ pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
                             cs1 = 0.f; cs2 = 0.f;
                         }
                     }
-                    stage_c = stage_c == WS_STAGES - 1 ? 0 : stage_c + 1;
+                    stage_c = stage_c == STG - 1 ? 0 : stage_c + 1;
                     ++q;
                 });
             }
@@ -339,7 +342,7 @@ pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
                     hl = fmaf(wq[SET], xh[SET][0], hl);
                     hr = fmaf(wq[SET], xh[SET][1], hr);
                 });
-                stage_c = stage_c == WS_STAGES - 1 ? 0 : stage_c + 1;
+                stage_c = stage_c == STG - 1 ? 0 : stage_c + 1;
             }
             // hand the row over (the vector wave read the previous row in the first chunk phase of this one)
 #pragma unroll
@@ -398,14 +401,14 @@ pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
         float* sbase = ring + istage * XCH;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            float* dst = dsto[p] >= 0 ? sbase + dsto[p] : ring + WS_STAGES * XCH;
+            float* dst = dsto[p] >= 0 ? sbase + dsto[p] : ring + STG * XCH;
             __builtin_amdgcn_global_load_lds((ws_gptr)(src + srcoff[p]), (ws_lptr)dst, 16, 0, 0);
         }
         if (ileft > 1) {
             const bool wrap = ic == NC - 1;
             isrc += wrap ? step_r : step_c;
             ic = wrap ? 0 : ic + 1;
-            istage = istage == WS_STAGES - 1 ? 0 : istage + 1;
+            istage = istage == STG - 1 ? 0 : istage + 1;
             --ileft;
         }
     };
@@ -468,7 +471,7 @@ pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
 
     if constexpr (!F16S) {
 #pragma unroll
-        for (int i = 0; i < WS_STAGES - 1; ++i) issue();
+        for (int i = 0; i < STG - 1; ++i) issue();
     }
     int stage_c = 0;
 
@@ -481,7 +484,7 @@ pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             // chunk landed for this wave (two newer chunks may be in flight), then for everyone
-            constexpr int NEWER = (WS_STAGES - 2) * P;
+            constexpr int NEWER = (STG - 2) * P;
             if constexpr (F16S) {
                 // (the split-f16 form: the matrix waves own the DMA stream and the LayerNorm statistics)
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -580,7 +583,7 @@ pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
                     }
                 }
             }
-            stage_c = stage_c == WS_STAGES - 1 ? 0 : stage_c + 1;
+            stage_c = stage_c == STG - 1 ? 0 : stage_c + 1;
         }
         // per-pixel LayerNorm constants of row r, read in the next row's first phase (behind its barrier)
         if (!F16S && have_row && a.ln_mode != 0) {
