@@ -27,16 +27,19 @@ typedef _Float16 gf_h2 __attribute__((ext_vector_type(2)));
 
 constexpr int GF_BN = 128, GF_BK = 32, GF_STAGES = 3, GF_XPIECE = 272, GF_SCR_LD = 36;
 
-__global__ void __launch_bounds__(64)
+// One block of four waves per 16-row tile (and matrix); wave w splits chunks w, w + 4, ...
+__global__ void __launch_bounds__(256)
 gemm_f16s_prep_kernel(const float* __restrict__ w, int64_t w_bs, int lda, int transA, const float* __restrict__ gamma,
                       const float* __restrict__ beta, const float* __restrict__ bias, int M, int K, int kch,
                       gf_h8* __restrict__ frag, int64_t frag_bs16, float* __restrict__ s, float* __restrict__ c) {
-    const int lane = threadIdx.x, m = lane & 15, g = lane >> 4;
+    __shared__ float red[2][4][16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, m = lane & 15, g = lane >> 4;
     const int mt = blockIdx.x, row = 16 * mt + m;
     const float* W = w + (int64_t)blockIdx.y * w_bs;
     gf_h8* out = frag + (int64_t)blockIdx.y * frag_bs16 + (int64_t)mt * kch * 2 * 64 + lane;
     float ssum = 0.f, csum = 0.f;
-    for (int kc = 0; kc < kch; ++kc) {
+#pragma unroll 2
+    for (int kc = wave; kc < kch; kc += 4) {
         gf_h8 hi, lo;
 #pragma unroll
         for (int idx = 0; idx < 8; ++idx) {
@@ -58,9 +61,11 @@ gemm_f16s_prep_kernel(const float* __restrict__ w, int64_t w_bs, int lda, int tr
     if (s != nullptr) {
         ssum += __shfl_xor(ssum, 16); csum += __shfl_xor(csum, 16);
         ssum += __shfl_xor(ssum, 32); csum += __shfl_xor(csum, 32);
-        if (g == 0 && row < M) {
-            s[row] = ssum;
-            c[row] = csum + (bias ? bias[row] : 0.f);
+        if (g == 0) { red[0][wave][m] = ssum; red[1][wave][m] = csum; }
+        __syncthreads();
+        if (wave == 0 && g == 0 && row < M) {
+            s[row] = (red[0][0][m] + red[0][1][m]) + (red[0][2][m] + red[0][3][m]);
+            c[row] = (red[1][0][m] + red[1][1][m]) + (red[1][2][m] + red[1][3][m]) + (bias ? bias[row] : 0.f);
         }
     }
 }
@@ -310,7 +315,7 @@ int gemm_f16s_prep_launch(const float* w, int64_t w_bs, int nb, int lda, int tra
     RST_REQUIRE(aligned16(frag) && frag_bs_bytes % 16 == 0, "gemm_f16s_prep: fragment buffer misaligned");
     RST_REQUIRE((s == nullptr) == (c == nullptr), "gemm_f16s_prep: s and c come together");
     const int mtiles = (int)cdiv(M, 16), kch = (int)cdiv(K, 32);
-    hipLaunchKernelGGL(gemm_f16s_prep_kernel, dim3((unsigned)mtiles, (unsigned)nb), dim3(64), 0, stream, w, w_bs, lda, transA,
+    hipLaunchKernelGGL(gemm_f16s_prep_kernel, dim3((unsigned)mtiles, (unsigned)nb), dim3(256), 0, stream, w, w_bs, lda, transA,
                        gamma, beta, bias, M, K, kch, static_cast<gf_h8*>(frag), frag_bs_bytes / 16, s, c);
     RST_LAUNCH_CHECK();
     return RST_OK;
