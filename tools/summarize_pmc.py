@@ -19,12 +19,17 @@ LN_FOLD_PER_PASS = 88          # two LayerNorm folds per TransformerBlock, 44 bl
 
 
 def group(name):
-    n = name.replace("void ", "")
+    n = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    mm = re.match(r"_ZN3rst(?:12_GLOBAL__N_1)?(\d+)", n)          # an unmangled name rocprofv3 left alone
+    if mm:
+        start = mm.end()
+        n = "rst::" + n[start:start + int(mm.group(1))] + "("
     m = re.match(r"rst::(\w+)<([^>]*)>", n)
     if not m:
         k = n.split("(")[0].replace("rst::", "")
         return {"attn_fold_kernel": "attn_fold", "attn_softmax_kernel": "attn_softmax", "ln_fold_weights_kernel": "ln_fold",
-                "reduce_slabs_vec_kernel": "reduce_slabs", "reduce_slabs_kernel": "reduce_slabs"}.get(k, k)
+                "reduce_slabs_vec_kernel": "reduce_slabs", "reduce_slabs_kernel": "reduce_slabs",
+                "gemm_f16s_prep_kernel": "gemm_f16s_prep", "conv3x3_f16s_prep_kernel": "conv3x3_f16s_prep"}.get(k, k)
     k, args = m.group(1), [a.strip() for a in m.group(2).split(",")]
     if k in ("gemm_nn_res_kernel", "gemm_nn_dma_kernel"):
         return "gemm_nn_ln" if args[3] == "true" else "gemm_nn"

@@ -5,6 +5,7 @@ usage: summarize_rocprof.py <kernel_stats.csv> <passes> [title] > profiles/<name
 `passes` = number of workload passes the profiled command ran (warm-up + timed +
 the profiling pass), used to express totals per pass."""
 import csv
+import re
 import sys
 
 
@@ -12,8 +13,9 @@ def main():
     path, passes = sys.argv[1], int(sys.argv[2])
     title = sys.argv[3] if len(sys.argv) > 3 else path
     rows = list(csv.DictReader(open(path)))
-    ours = [r for r in rows if "rst::" in r["Name"]]
-    other = [r for r in rows if "rst::" not in r["Name"]]
+    mine = lambda r: "rst::" in r["Name"] or r["Name"].startswith("_ZN3rst")
+    ours = [r for r in rows if mine(r)]
+    other = [r for r in rows if not mine(r)]
     tot_ours = sum(float(r["TotalDurationNs"]) for r in ours) / 1e6
     tot_other = sum(float(r["TotalDurationNs"]) for r in other) / 1e6
     print(f"# {title}\n")
@@ -22,7 +24,10 @@ def main():
     print("| kernel | calls | calls/pass | avg us | total ms | ms/pass |")
     print("|---|---|---|---|---|---|")
     for r in sorted(ours, key=lambda r: -float(r["TotalDurationNs"])):
-        name = r["Name"].replace("void ", "").split("(")[0]
+        name = r["Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
+        mm = re.match(r"_ZN3rst(?:12_GLOBAL__N_1)?(\d+)", name)
+        if mm:
+            name = "rst::" + name[mm.end():mm.end() + int(mm.group(1))]
         c = int(r["Calls"])
         t = float(r["TotalDurationNs"]) / 1e6
         print(f"| `{name}` | {c} | {c / passes:.1f} | {float(r['AverageNs']) / 1e3:.1f} | {t:.2f} | {t / passes:.3f} |")
