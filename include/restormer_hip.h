@@ -347,6 +347,17 @@ size_t rst_bf16_block_workspace_bytes(const rst_block_desc* desc);
 int rst_bf16_block_fwd(const rst_block_desc* desc, const rst_block_params* params,
                        const void* prepared, const void* x_packed, void* y_packed,
                        void* workspace, size_t workspace_bytes, void* stream);
+/* Its backward (what autograd derives from model/Restromer.py:163-167 when the   */
+/* block runs on bf16 tensors): from the block's packed INPUT and the packed       */
+/* gradient of its output, the packed gradient of the input and the fp32 gradients  */
+/* of all parameters (overwritten).  The block is evaluated again inside, so        */
+/* nothing but x has to be kept from the forward pass.  dx must not alias x or dy.  */
+/* prepared: as for rst_bf16_block_fwd (the forward pass's buffer if the parameters */
+/* have not changed since), or NULL.  Same shape limits as rst_bf16_block_fwd.      */
+size_t rst_bf16_block_bwd_workspace_bytes(const rst_block_desc* desc);
+int rst_bf16_block_bwd(const rst_block_desc* desc, const rst_block_params* params, const void* prepared,
+                       const void* x_packed, const void* dy_packed, void* dx_packed,
+                       rst_block_grads* grads, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Dataset item on the GPU -- replaces LazyRAWDataset.__getitem__,             */

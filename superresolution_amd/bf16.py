@@ -14,7 +14,7 @@ from typing import Dict, Optional
 import torch
 
 from . import _lib
-from ._lib import BlockParams, PARAM_FIELDS, check
+from ._lib import BlockGrads, BlockParams, PARAM_FIELDS, check
 from .ops import _fill, _ptr, _stream, make_desc, workspace
 
 
@@ -180,14 +180,14 @@ def cat(a: Packed, b: Packed) -> Packed:
 class _StageFn(torch.autograd.Function):
     """A run of TransformerBlocks (one `nn.Sequential` of the network) on bf16 activations, differentiable.
 
-    Forward: the packed bf16 inference kernels (`rst_bf16_block_fwd`, fused, nothing kept but each block's INPUT in
-    packed bf16 -- 2 bytes per element and block instead of the ~26 fp32 values per element that the fp32 training
-    forward keeps).  Backward, block by block in reverse: the kept input is unpacked to fp32, the block's fp32
-    training forward is run again on it (`rst_block_fwd` with a saved buffer: activation recomputation) and
-    `rst_block_bwd` gives the input and parameter gradients in fp32.  So: bf16 storage, fp32 sums, fp32 parameters and
-    gradients; the gradient is that of the fp32 block evaluated at the bf16-rounded activations.  Inside a stage the
-    gradient between blocks stays fp32; between stages it is bf16 like the activations (what autograd does for bf16
-    tensors).  x: (B, C, H, W) bf16."""
+    Forward: the packed bf16 inference kernels (`rst_bf16_block_fwd`, fused); nothing is kept but each block's INPUT
+    in packed bf16 -- 2 bytes per element and block instead of the ~26 fp32 values per element that the fp32
+    training forward keeps.  Backward, block by block in reverse: `rst_bf16_block_bwd` evaluates the block again on
+    the kept input (activation recomputation, bf16 storage) and returns the packed bf16 gradient of the input and
+    the fp32 gradients of the parameters.  So: bf16 activations and activation gradients, fp32 sums, fp32 parameters
+    and parameter gradients.  ``RST_BF16_BWD=fp32`` switches the backward to the fp32 kernels on the unpacked input
+    (`ops.block_recompute_backward`: the gradient of the fp32 block at the bf16-rounded activations).
+    x: (B, C, H, W) bf16."""
 
     @staticmethod
     def forward(ctx, x, metas, caches, *flat):
@@ -203,30 +203,65 @@ class _StageFn(torch.autograd.Function):
             out = Packed(torch.empty_like(p.data), p.C)
             _block_into(lib, p, out, heads, hidden, params, caches[i])
             p = out
-        ctx.metas, ctx.shape = metas, tuple(x.shape)
+        ctx.metas, ctx.shape, ctx.caches = metas, tuple(x.shape), caches
         ctx.present = [t is not None for t in flat]
         ctx.save_for_backward(*kept, *[t for t in flat if t is not None])
         return unpack(p, torch.bfloat16)
 
     @staticmethod
     def backward(ctx, dy):
-        from . import ops
+        import os
         lib = _lib.load()
         nb = len(ctx.metas)
         kept, rest = ctx.saved_tensors[:nb], iter(ctx.saved_tensors[nb:])
         flat = [next(rest) if pr else None for pr in ctx.present]
         B, C, H, W = ctx.shape
-        g = dy.float().contiguous()
         n = len(PARAM_FIELDS)
         grads = [None] * len(flat)
+        if os.environ.get("RST_BF16_BWD", "bf16") == "fp32":
+            from . import ops
+            g = dy.float().contiguous()
+            for i in reversed(range(nb)):
+                heads, hidden = ctx.metas[i]
+                params = dict(zip(PARAM_FIELDS, flat[i * n:(i + 1) * n]))
+                x32 = unpack(Packed(kept[i], C), torch.float32)
+                g, pg = ops.block_recompute_backward(x32, g, heads, hidden, params)
+                for j, name in enumerate(PARAM_FIELDS):
+                    grads[i * n + j] = pg[name]
+            return (g.to(torch.bfloat16), None, None) + tuple(grads)
+        g = pack(dy.contiguous())
         for i in reversed(range(nb)):
             heads, hidden = ctx.metas[i]
             params = dict(zip(PARAM_FIELDS, flat[i * n:(i + 1) * n]))
-            x32 = unpack(Packed(kept[i], C), torch.float32)
-            g, pg = ops.block_recompute_backward(x32, g, heads, hidden, params)
+            g, pg = block_backward(Packed(kept[i], C), g, heads, hidden, params, ctx.caches[i])
             for j, name in enumerate(PARAM_FIELDS):
                 grads[i * n + j] = pg[name]
-        return (g.to(torch.bfloat16), None, None) + tuple(grads)
+        return (unpack(g, torch.bfloat16), None, None) + tuple(grads)
+
+
+def block_backward(x: Packed, dy: Packed, heads: int, hidden: int, params: Dict[str, Optional[torch.Tensor]],
+                   cache: Optional[PreparedCache] = None):
+    """Gradients of one TransformerBlock from its packed bf16 input and the packed gradient of its output
+    (`rst_bf16_block_bwd`).  Returns (dx packed, {parameter name: fp32 gradient or None}).  With the block's `cache`
+    the weights prepared for the forward pass are used again (they are rebuilt if a parameter changed since)."""
+    lib = _lib.load()
+    B, C, H, W = x.shape
+    tensors = {n: _f32(None if params.get(n) is None else params[n].detach(), n) for n in PARAM_FIELDS}
+    desc = make_desc(B, C, H, W, heads, hidden, tensors["norm1_bias"] is not None, tensors["qkv_bias"] is not None)
+    nb = lib.rst_bf16_block_bwd_workspace_bytes(ctypes.byref(desc))
+    if nb == 0:
+        raise RuntimeError("bf16 block backward: " + lib.rst_last_error().decode("utf-8", "replace"))
+    par = _fill(BlockParams(), tensors)
+    grads = {n: (None if t is None else torch.empty_like(t)) for n, t in tensors.items()}
+    gr = _fill(BlockGrads(), grads)
+    prepared = None
+    if cache is not None:
+        prepared = cache.get(lib, desc, par, {n: params.get(n) for n in PARAM_FIELDS}, x.data.device)
+    ws = workspace(nb, x.data.device)
+    dx = Packed(torch.empty_like(x.data), x.C)
+    check(lib.rst_bf16_block_bwd(ctypes.byref(desc), ctypes.byref(par), _ptr(prepared), _ptr(x.data), _ptr(dy.data), _ptr(dx.data), ctypes.byref(gr),
+                                 _ptr(ws), ws.numel(), _stream()), "rst_bf16_block_bwd")
+    return dx, grads
 
 
 def _block_into(lib, src: Packed, dst: Packed, heads, hidden, params, cache):

@@ -253,6 +253,291 @@ static int pk_block_fwd(const rst_block_desc* d, const rst_block_params* p, cons
     return RST_OK;
 }
 
+// ================================ backward ==========================================
+// Gradients of one block from its packed bf16 input and output gradient.  The block is evaluated again first (the
+// unfused kernels, every intermediate kept in bf16 in the workspace), then walked backwards: the data gradients are
+// 1x1 convolutions with transposed weights (gemm_pk; contractions over more than 480 channels in slices that add
+// through the output) and depthwise convolutions with rotated taps; the weight gradients are products over the pixels
+// (wgrad_pk); the LayerNorm in front of a 1x1 convolution is differentiated through the product with the normalised
+// tensor (lnlin_grads).  Parameter gradients are fp32.
+namespace {
+
+constexpr int PK_KSLICE = 480;          // widest contraction of one gemm_pk launch
+
+// fragments of A[M positions][K positions] in slices of the contraction
+struct PkSliced {
+    int nslices;
+    PkWeight w[4];
+    int kpos0[4], krange[4];
+};
+PkSliced pk_sliced_shape(int Mpos, int Kpos) {
+    PkSliced s{};
+    s.nslices = (int)cdiv(Kpos, PK_KSLICE);
+    for (int i = 0; i < s.nslices; ++i) {
+        s.kpos0[i] = i * PK_KSLICE;
+        s.krange[i] = Kpos - s.kpos0[i] < PK_KSLICE ? Kpos - s.kpos0[i] : PK_KSLICE;
+        s.w[i] = pk_weight_shape(Mpos, s.krange[i], NOSEG, NOSEG);
+    }
+    return s;
+}
+void pk_sliced_carve(PkSliced& s, Carve& cv, int nb) {
+    for (int i = 0; i < s.nslices; ++i) s.w[i].frag = cv.halves(s.w[i].frag_elems() * nb);
+}
+// Y[b] = A X[b] slice by slice; X holds the contraction's positions as channel blocks
+int pk_sliced_gemm(const PkSliced& s, const bf16_t* x, int64_t x_bs, bf16_t* y, int64_t y_bs, int B, int64_t N, int64_t a_bs,
+                   hipStream_t stream) {
+    for (int i = 0; i < s.nslices; ++i) {
+        GemmPk g = pk_gemm_args(s.w[i], x + (int64_t)(s.kpos0[i] / 8) * N * 8, x_bs, y, y_bs, B, N);
+        g.a_bs = a_bs;
+        if (i > 0) { g.R = y; g.r_bs = y_bs; }
+        RST_TRY(gemm_pk_launch(g, stream));
+    }
+    return RST_OK;
+}
+
+struct PkBwdBufs {
+    PkBlockBufs f;                                  // forward: prepared weights and attention scratch
+    bf16_t *t, *qkv, *x1, *u, *d, *g;               // recomputed intermediates
+    bf16_t *dg, *dd, *du, *xh, *dn, *dx1, *dqkv, *dt;
+    float *ghat, *nq, *nk;
+    float *P, *Eq, *Dq, *Dk, *dGG, *dtemp_row, *dtemp_b, *dwo_b, *mats;
+    PkSliced wpoutT, wpinT, wqkvT;
+    PkWeight wmfT, wmat;
+    float *dw_qkv_flip, *dw_ffn_flip;
+    float *part, *red, *dw_part, *dw_red;          // red: [M][K] sums, then M row sums
+    size_t part_floats, dw_floats;
+};
+
+WgradPk pk_wgrad_shape(int Ab, int Bb, int B, int64_t N, bool with_rowsum) {
+    WgradPk g{};
+    g.Ab = Ab; g.Bb = Bb; g.B = B; g.N = N; g.with_rowsum = with_rowsum ? 1 : 0;
+    wgrad_pk_plan(&g);
+    return g;
+}
+
+void pk_bwd_carve(const rst_block_desc* d, Carve& cv, PkBwdBufs& b) {
+    const int C = d->C, Hd = d->hidden, Hp = pad8(Hd), heads = d->heads, c = C / heads, B = d->B;
+    const int64_t N = (int64_t)d->H * d->W;
+    const size_t bn = (size_t)B * N;
+    pk_block_carve_prepared(d, cv, b.f);
+    pk_block_carve(d, cv, b.f);                      // (its buf1 / buf2 are not used here)
+    b.t = cv.halves(bn * 3 * C); b.qkv = cv.halves(bn * 3 * C); b.x1 = cv.halves(bn * C);
+    b.u = cv.halves(bn * 2 * Hp); b.d = cv.halves(bn * 2 * Hp); b.g = cv.halves(bn * Hp);
+    b.dg = cv.halves(bn * Hp); b.dd = cv.halves(bn * 2 * Hp); b.du = cv.halves(bn * 2 * Hp);
+    b.xh = cv.halves(bn * C); b.dn = cv.halves(bn * C); b.dx1 = cv.halves(bn * C);
+    b.dqkv = cv.halves(bn * 3 * C); b.dt = cv.halves(bn * 3 * C);
+    const size_t BH = (size_t)B * heads;
+    b.ghat = cv.floats(BH * c * c); b.nq = cv.floats((size_t)B * C); b.nk = cv.floats((size_t)B * C);
+    b.P = cv.floats((size_t)B * C * C);
+    b.Eq = cv.floats(BH * c * c); b.Dq = cv.floats((size_t)B * C); b.Dk = cv.floats((size_t)B * C);
+    b.dGG = cv.floats(BH * c * c); b.dtemp_row = cv.floats((size_t)B * C); b.dtemp_b = cv.floats(BH);
+    b.dwo_b = cv.floats((size_t)B * C * C);
+    b.mats = cv.floats((size_t)B * 4 * C * C);
+    b.wpoutT = pk_sliced_shape(Hp, C);        pk_sliced_carve(b.wpoutT, cv, 1);
+    b.wpinT = pk_sliced_shape(C, 2 * Hp);     pk_sliced_carve(b.wpinT, cv, 1);
+    b.wqkvT = pk_sliced_shape(C, 3 * C);      pk_sliced_carve(b.wqkvT, cv, 1);
+    b.wmfT = pk_plain_weight(C, C);           b.wmfT.frag = cv.halves(b.wmfT.frag_elems() * B);
+    b.wmat = pk_plain_weight(C, C);           b.wmat.frag = cv.halves(b.wmat.frag_elems() * 4 * B);
+    b.dw_qkv_flip = cv.floats((size_t)(3 * C / 8) * 80);
+    b.dw_ffn_flip = cv.floats((size_t)(2 * Hp / 8) * 80);
+    // the widest of the products over the pixels
+    const int shapes[4][2] = {{C / 8, Hp / 8}, {2 * Hp / 8, C / 8}, {C / 8, C / 8}, {3 * C / 8, C / 8}};
+    b.part_floats = 0;
+    for (const auto& sh : shapes) {
+        const WgradPk g = pk_wgrad_shape(sh[0], sh[1], B, N, true);
+        b.part_floats = b.part_floats > wgrad_pk_partial_floats(g) ? b.part_floats : wgrad_pk_partial_floats(g);
+    }
+    b.part = cv.floats(b.part_floats);
+    const int wmax = 3 * C > 2 * Hp ? 3 * C : 2 * Hp;
+    b.red = cv.floats((size_t)wmax * (C > Hp ? C : Hp) + wmax);
+    const size_t dwa = dw_wgrad_pk_partial_floats(B, 3 * C / 8, d->H, d->W), dwb = dw_wgrad_pk_partial_floats(B, 2 * Hp / 8, d->H, d->W);
+    b.dw_floats = dwa > dwb ? dwa : dwb;
+    b.dw_part = cv.floats(b.dw_floats);
+    b.dw_red = cv.floats((size_t)(wmax / 8) * 80);
+}
+size_t pk_block_bwd_ws_bytes(const rst_block_desc* d) {
+    Carve cv(nullptr); PkBwdBufs b{};
+    pk_bwd_carve(d, cv, b);
+    return cv.total();
+}
+
+// out = sum over (samples and) splits of the product over the pixels, [Ab*8][Bb*8] (+ the Ab*8 row sums of A behind
+// it when asked); `per_sample`: one such record per sample
+int pk_wgrad(const bf16_t* a, int64_t a_bs, int Ab, const bf16_t* bm, int64_t b_bs, int Bb, int B, int64_t N, bool per_sample,
+             bool with_rowsum, float* out, PkBwdBufs& b, hipStream_t stream) {
+    WgradPk g = pk_wgrad_shape(Ab, Bb, B, N, with_rowsum);
+    g.A = a; g.a_bs = a_bs; g.Bm = bm; g.b_bs = b_bs;
+    g.partial = b.part;
+    RST_REQUIRE(wgrad_pk_partial_floats(g) <= b.part_floats, "bf16 block backward: weight-gradient scratch too small");
+    RST_TRY(wgrad_pk_launch(g, stream));
+    const int64_t rec = (int64_t)Ab * 8 * Bb * 8 + (with_rowsum ? Ab * 8 : 0);
+    return reduce_slabs_launch(b.part, out, rec, per_sample ? B : 1, per_sample ? g.splits : B * g.splits, 0, stream);
+}
+
+}  // namespace
+
+static int pk_block_bwd(const rst_block_desc* d, const rst_block_params* p, const void* prepared, const bf16_t* x, const bf16_t* dy,
+                        bf16_t* dx, rst_block_grads* gr, void* ws, size_t ws_bytes, hipStream_t stream) {
+    RST_REQUIRE(x && dy && dx && p && gr, "bf16 block backward: null operand");
+    RST_REQUIRE(gr->norm1_weight && gr->norm2_weight && gr->temperature && gr->qkv_weight && gr->qkv_dw_weight && gr->proj_weight &&
+                gr->pin_weight && gr->ffn_dw_weight && gr->pout_weight, "bf16 block backward: null gradient buffer");
+    RST_REQUIRE(!d->ln_with_bias || (gr->norm1_bias && gr->norm2_bias), "bf16 block backward: null LayerNorm bias gradient buffer");
+    RST_REQUIRE(!d->conv_bias || (gr->qkv_bias && gr->qkv_dw_bias && gr->proj_bias && gr->pin_bias && gr->ffn_dw_bias && gr->pout_bias),
+                "bf16 block backward: null bias gradient buffer");
+    if (ws == nullptr || ws_bytes < pk_block_bwd_ws_bytes(d))
+        return fail(RST_ERR_WORKSPACE, "bf16 block backward: workspace %zu < %zu bytes", ws_bytes, pk_block_bwd_ws_bytes(d));
+    const int C = d->C, Hd = d->hidden, Hp = pad8(Hd), heads = d->heads, c = C / heads, B = d->B;
+    const int64_t N = (int64_t)d->H * d->W;
+    const int64_t cn = (int64_t)C * N, hn = (int64_t)Hp * N;
+    const bool cb = d->conv_bias != 0;
+    const int wb = d->ln_with_bias ? 1 : 0;
+    const int ln_mode = wb ? 1 : 2;
+    Carve cv(ws); PkBwdBufs b{};
+    pk_bwd_carve(d, cv, b);
+    if (prepared != nullptr) {
+        Carve cp(const_cast<void*>(prepared));
+        pk_block_carve_prepared(d, cp, b.f);             // the forward pass's prepared weights: nothing changed since
+    } else {
+        RST_TRY(pk_block_prepare(d, p, b.f, stream));
+    }
+
+    // ---------------- forward again, everything kept ----------------
+    {
+        GemmPk g = pk_gemm_args(b.f.wqkv, x, cn, b.t, 3 * cn, B, N);
+        g.ln_mode = ln_mode; g.ln_s = b.f.wqkv.s; g.ln_c = b.f.wqkv.c;
+        RST_TRY(gemm_pk_launch(g, stream));
+        DwPk a{};
+        a.x = b.t; a.x_bs = 3 * cn; a.wp = b.f.dw_qkv; a.y = b.qkv; a.y_bs = 3 * cn;
+        a.B = B; a.Cb = 3 * C / 8; a.H = d->H; a.W = d->W; a.gate = 0;
+        RST_TRY(dw_pk_launch(a, stream));
+    }
+    {
+        GramPk g{};
+        g.Q = b.qkv; g.Kx = b.qkv + cn; g.bs = 3 * cn; g.cb = c / 8; g.heads = heads; g.B = B; g.N = N;
+        g.splits = b.f.splits; g.chunk_px = b.f.chunk; g.partial = b.f.gram_part; g.sqq = b.f.sqq_part; g.sqk = b.f.sqk_part;
+        RST_TRY(gram_pk_launch(g, stream));
+        RST_TRY(reduce_slabs_launch(b.f.gram_part, b.f.gram_red, (int64_t)c * c, B * heads, b.f.splits, 0, stream));
+        RST_TRY(reduce_slabs_launch(b.f.sqq_part, b.f.sqq_red, c, B * heads, b.f.splits, 0, stream));
+        RST_TRY(reduce_slabs_launch(b.f.sqk_part, b.f.sqk_red, c, B * heads, b.f.splits, 0, stream));
+        RST_TRY(attn_softmax_launch(b.f.gram_red, b.f.sqq_red, b.f.sqk_red, p->temperature, b.f.attn, b.ghat, b.nq, b.nk,
+                                    B, heads, c, 1, stream));
+        RST_TRY(attn_fold_launch(p->proj_weight, b.f.attn, b.f.mfold, B, C, heads, c, stream));
+        RST_TRY(pk_prep_a_launch(b.f.mfold, (int64_t)C * C, C, nullptr, C, C, NOSEG, NOSEG, b.f.wattn.ntiles, b.f.wattn.KS, b.f.wattn.frag,
+                                 (int64_t)b.f.wattn.frag_elems(), B, stream));
+        if (cb) RST_TRY(pk_prep_sc_launch(p->proj_weight, C, nullptr, nullptr, p->proj_bias, C, C, NOSEG, NOSEG, b.f.wattn.npos,
+                                          b.f.wattn.s, b.f.wattn.c, stream));
+        GemmPk m = pk_gemm_args(b.f.wattn, b.qkv + 2 * cn, 3 * cn, b.x1, cn, B, N);
+        m.a_bs = (int64_t)b.f.wattn.frag_elems() / 8;
+        m.R = x; m.r_bs = cn;
+        m.ln_c = cb ? b.f.wattn.c : nullptr;
+        RST_TRY(gemm_pk_launch(m, stream));
+    }
+    {
+        GemmPk g = pk_gemm_args(b.f.wpin, b.x1, cn, b.u, 2 * hn, B, N);
+        g.ln_mode = ln_mode; g.ln_s = b.f.wpin.s; g.ln_c = b.f.wpin.c;
+        RST_TRY(gemm_pk_launch(g, stream));
+        DwPk a{};
+        a.x = b.u; a.x_bs = 2 * hn; a.wp = b.f.dw_ffn; a.y = b.d; a.y_bs = 2 * hn;
+        a.B = B; a.Cb = 2 * Hp / 8; a.H = d->H; a.W = d->W; a.gate = 0;
+        RST_TRY(dw_pk_launch(a, stream));
+        RST_TRY(gate_fwd_pk_launch(b.d, b.g, B, Hp / 8, N, stream));
+    }
+
+    // ---------------- weights of the data gradients ----------------
+    {
+        PrepAtJobs jobs{};
+        auto add = [&](const PkSliced& sl, const float* w, int ldw, int M, int Ksrc, int kseg, int kseg_pad) {
+            for (int i = 0; i < sl.nslices; ++i) {
+                PrepAtJob& q = jobs.job[jobs.n++];
+                q.w = w; q.ldw = ldw; q.transA = 1; q.M = M; q.mseg = NOSEG; q.mseg_pad = NOSEG;
+                q.Ksrc = Ksrc; q.kseg = kseg; q.kseg_pad = kseg_pad; q.kpos0 = sl.kpos0[i]; q.Krange = sl.krange[i];
+                q.ntiles = sl.w[i].ntiles; q.KS = sl.w[i].KS; q.frag = sl.w[i].frag;
+            }
+        };
+        RST_REQUIRE(b.wpoutT.nslices + b.wpinT.nslices + b.wqkvT.nslices <= 8, "bf16 block backward: too many weight slices");
+        add(b.wpoutT, p->pout_weight, Hd, Hd, C, NOSEG, NOSEG);          // dg = Wout^T dy: rows = hidden positions
+        add(b.wpinT, p->pin_weight, C, C, 2 * Hd, Hd, -1);              // dn2 = Win^T du over the interleaved 2 Hp positions
+        add(b.wqkvT, p->qkv_weight, C, C, 3 * C, NOSEG, NOSEG);         // dn1 = Wqkv^T dt
+        RST_TRY(pk_prep_at_jobs_launch(jobs, stream));
+    }
+    RST_TRY(pk_prep_dw_launch(p->qkv_dw_weight, nullptr, 3 * C, NOSEG, NOSEG, 3 * C / 8, b.dw_qkv_flip, stream, 1));
+    RST_TRY(pk_prep_dw_launch(p->ffn_dw_weight, nullptr, 2 * Hd, Hd, -1, 2 * Hp / 8, b.dw_ffn_flip, stream, 1));
+
+    // ---------------- GDFN: y = x1 + Wout (gelu(d1) d2), d = dw(Win LN2(x1)) ----------------
+    RST_TRY(pk_wgrad(dy, cn, C / 8, b.g, hn, Hp / 8, B, N, false, cb, b.red, b, stream));
+    RST_TRY(crop2d_launch(b.red, Hp, gr->pout_weight, C, Hd, stream));
+    if (cb) RST_HIP(hipMemcpyAsync(gr->pout_bias, b.red + (size_t)C * Hp, sizeof(float) * C, hipMemcpyDeviceToDevice, stream));
+    RST_TRY(pk_sliced_gemm(b.wpoutT, dy, cn, b.dg, hn, B, N, 0, stream));
+    RST_TRY(gate_bwd_pk_launch(b.dg, b.d, b.dd, B, Hp / 8, N, stream));
+    {
+        DwWgradPk a{};
+        a.dy = b.dd; a.dy_bs = 2 * hn; a.x = b.u; a.x_bs = 2 * hn; a.B = B; a.Cb = 2 * Hp / 8; a.H = d->H; a.W = d->W;
+        a.partial = b.dw_part;
+        RST_TRY(dw_wgrad_pk_launch(a, b.dw_red, stream));
+        RST_TRY(dw_grad_unpack_launch(b.dw_red, gr->ffn_dw_weight, cb ? gr->ffn_dw_bias : nullptr, 2 * Hd, Hd, -1, 2 * Hp / 8, stream));
+        DwPk w{};
+        w.x = b.dd; w.x_bs = 2 * hn; w.wp = b.dw_ffn_flip; w.y = b.du; w.y_bs = 2 * hn;
+        w.B = B; w.Cb = 2 * Hp / 8; w.H = d->H; w.W = d->W; w.gate = 0;
+        RST_TRY(dw_pk_launch(w, stream));
+    }
+    RST_TRY(ln_fwd_pk_launch(b.x1, b.xh, B, C / 8, N, wb, stream));
+    RST_TRY(pk_wgrad(b.du, 2 * hn, 2 * Hp / 8, b.xh, cn, C / 8, B, N, false, true, b.red, b, stream));
+    RST_TRY(lnlin_grads_launch(b.red, b.red + (size_t)2 * Hp * C, p->pin_weight, p->norm2_weight, wb ? p->norm2_bias : nullptr, gr->pin_weight,
+                               cb ? gr->pin_bias : nullptr, gr->norm2_weight, wb ? gr->norm2_bias : nullptr, 2 * Hd, C, Hd, -1, stream));
+    RST_TRY(pk_sliced_gemm(b.wpinT, b.du, 2 * hn, b.dn, cn, B, N, 0, stream));
+    RST_TRY(ln_bwd_pk_launch(b.dn, b.x1, p->norm2_weight, dy, b.dx1, B, C / 8, N, wb, stream));
+
+    // ---------------- MDTA: x1 = x + M_b v, M_b = Wo blockdiag(softmax) ----------------
+    const bf16_t* q = b.qkv; const bf16_t* k = b.qkv + cn; const bf16_t* v = b.qkv + 2 * cn;
+    RST_TRY(pk_wgrad(b.dx1, cn, C / 8, v, 3 * cn, C / 8, B, N, true, false, b.P, b, stream));
+    if (cb) {
+        // the projection's bias gradient: the sums of dx1's rows over everything (the product with its own rows is a
+        // by-product nobody reads)
+        RST_TRY(pk_wgrad(b.dx1, cn, C / 8, b.dx1, cn, 1, B, N, false, true, b.red, b, stream));
+        RST_HIP(hipMemcpyAsync(gr->proj_bias, b.red + (size_t)C * 8, sizeof(float) * C, hipMemcpyDeviceToDevice, stream));
+    }
+    RST_TRY(attn_bwd_small_launch(b.P, p->proj_weight, b.f.attn, b.ghat, b.nq, b.nk, p->temperature, b.Eq, b.Dq, b.Dk,
+                                  b.dGG, b.dtemp_row, b.dtemp_b, b.dwo_b, B, C, heads, c, stream));
+    RST_TRY(reduce_slabs_launch(b.dwo_b, gr->proj_weight, (int64_t)C * C, 1, B, 0, stream));
+    RST_TRY(reduce_slabs_launch(b.dtemp_b, gr->temperature, heads, 1, B, 0, stream));
+    RST_TRY(attn_bwd_mats_launch(b.Eq, b.Dq, b.Dk, b.mats, B, C, c, stream));
+    const int64_t fe = (int64_t)b.wmat.frag_elems();
+    RST_TRY(pk_prep_a_launch(b.mats, (int64_t)C * C, C, nullptr, C, C, NOSEG, NOSEG, b.wmat.ntiles, b.wmat.KS, b.wmat.frag, fe, 4 * B, stream));
+    RST_TRY(pk_prep_at_launch(b.f.mfold, (int64_t)C * C, C, 1, C, NOSEG, NOSEG, C, NOSEG, NOSEG, 0, C, b.wmfT.ntiles, b.wmfT.KS,
+                              b.wmfT.frag, (int64_t)b.wmfT.frag_elems(), B, stream));
+    {
+        // dq = BD(Eq) k + diag(Dq) q;  dk = BD(Eq)^T q + diag(Dk) k;  dv = M^T dx1
+        const bf16_t* src[4] = {k, q, q, k};
+        for (int j = 0; j < 4; ++j) {
+            bf16_t* out = b.dqkv + (j / 2) * cn;
+            GemmPk g = pk_gemm_args(b.wmat, src[j], 3 * cn, out, 3 * cn, B, N);
+            g.A = b.wmat.frag + (int64_t)j * fe; g.a_bs = 4 * fe / 8;
+            if (j & 1) { g.R = out; g.r_bs = 3 * cn; }
+            RST_TRY(gemm_pk_launch(g, stream));
+        }
+        GemmPk g = pk_gemm_args(b.wmfT, b.dx1, cn, b.dqkv + 2 * cn, 3 * cn, B, N);
+        g.a_bs = (int64_t)b.wmfT.frag_elems() / 8;
+        RST_TRY(gemm_pk_launch(g, stream));
+    }
+    {
+        DwWgradPk a{};
+        a.dy = b.dqkv; a.dy_bs = 3 * cn; a.x = b.t; a.x_bs = 3 * cn; a.B = B; a.Cb = 3 * C / 8; a.H = d->H; a.W = d->W;
+        a.partial = b.dw_part;
+        RST_TRY(dw_wgrad_pk_launch(a, b.dw_red, stream));
+        RST_TRY(dw_grad_unpack_launch(b.dw_red, gr->qkv_dw_weight, cb ? gr->qkv_dw_bias : nullptr, 3 * C, NOSEG, NOSEG, 3 * C / 8, stream));
+        DwPk w{};
+        w.x = b.dqkv; w.x_bs = 3 * cn; w.wp = b.dw_qkv_flip; w.y = b.dt; w.y_bs = 3 * cn;
+        w.B = B; w.Cb = 3 * C / 8; w.H = d->H; w.W = d->W; w.gate = 0;
+        RST_TRY(dw_pk_launch(w, stream));
+    }
+    RST_TRY(ln_fwd_pk_launch(x, b.xh, B, C / 8, N, wb, stream));
+    RST_TRY(pk_wgrad(b.dt, 3 * cn, 3 * C / 8, b.xh, cn, C / 8, B, N, false, true, b.red, b, stream));
+    RST_TRY(lnlin_grads_launch(b.red, b.red + (size_t)3 * C * C, p->qkv_weight, p->norm1_weight, wb ? p->norm1_bias : nullptr, gr->qkv_weight,
+                               cb ? gr->qkv_bias : nullptr, gr->norm1_weight, wb ? gr->norm1_bias : nullptr, 3 * C, C, NOSEG, NOSEG, stream));
+    RST_TRY(pk_sliced_gemm(b.wqkvT, b.dt, 3 * cn, b.dn, cn, B, N, 0, stream));
+    return ln_bwd_pk_launch(b.dn, x, p->norm1_weight, b.dx1, dx, B, C / 8, N, wb, stream);
+}
+
 }  // namespace rst
 
 using namespace rst;
@@ -268,6 +553,18 @@ int rst_bf16_pack(const void* x, int32_t x_is_fp32, void* y_packed, int32_t B, i
 }
 int rst_bf16_unpack(const void* x_packed, void* y, int32_t y_is_fp32, int32_t B, int32_t C, int64_t N, void* stream) {
     return pk_unpack_launch(static_cast<const bf16_t*>(x_packed), y, y_is_fp32, B, C, N, static_cast<hipStream_t>(stream));
+}
+
+size_t rst_bf16_block_bwd_workspace_bytes(const rst_block_desc* desc) {
+    if (check_pk_desc(desc) != RST_OK) return 0;
+    return pk_block_bwd_ws_bytes(desc);
+}
+int rst_bf16_block_bwd(const rst_block_desc* desc, const rst_block_params* params, const void* prepared, const void* x_packed,
+                       const void* dy_packed, void* dx_packed, rst_block_grads* grads, void* workspace, size_t workspace_bytes,
+                       void* stream) {
+    RST_TRY(check_pk_desc(desc));
+    return pk_block_bwd(desc, params, prepared, static_cast<const bf16_t*>(x_packed), static_cast<const bf16_t*>(dy_packed),
+                        static_cast<bf16_t*>(dx_packed), grads, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 int rst_bf16_to_channels_last(const void* x_packed, void* y_nhwc, int32_t B, int32_t C, int64_t N, void* stream) {

@@ -10,46 +10,9 @@
 // pixel, and the Gram product q k^T over the pixels transposes its operands on the way out of LDS with
 // ds_read_b64_tr_b16.
 #include "kernels.hpp"
+#include "bf16_common.hpp"
 
 namespace rst {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
-__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
-__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {     // round to nearest even
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
-__device__ __forceinline__ void unpack8(const u32x4 w, float* v) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { v[2 * i] = bf_lo(w[i]); v[2 * i + 1] = bf_hi(w[i]); }
-}
-__device__ __forceinline__ u32x4 pack8(const float* v) {
-    u32x4 w;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = pack_bf16(v[2 * i], v[2 * i + 1]);
-    return w;
-}
-__device__ __forceinline__ uint16_t to_bf16_bits(float x) { return (uint16_t)(pack_bf16(x, 0.f) & 0xffffu); }
-
-// Position p of a packed buffer -> channel of the source tensor, or -1 for padding.  The source channels come in
-// segments of `seg` channels, each padded to `seg_pad` positions (the two halves of the gated feed-forward).
-// seg_pad < 0: two segments interleaved in groups of four -- block j of 8 positions holds channels 4j..4j+3 of the
-// first segment and then the same channels of the second (the gated feed-forward: a lane that owns one block has
-// both factors of gelu(x1) * x2).
-__device__ __forceinline__ int src_channel(int p, int seg, int seg_pad, int total) {
-    if (seg_pad < 0) {
-        const int i = 4 * (p >> 3) + (p & 3), half = (p >> 2) & 1;
-        return (i < seg && half * seg + i < total) ? half * seg + i : -1;
-    }
-    const int q = p / seg_pad, r = p % seg_pad;
-    const int ch = q * seg + r;
-    return (r < seg && ch < total) ? ch : -1;
-}
 
 // ---- weight preparation -----------------------------------------------------------------------------------
 // frag[b][mt][ks][lane][j] = A operand of m-tile mt, k-step ks:  row = permuted position, k = 32 ks + 8 (lane>>4) + j
@@ -104,13 +67,13 @@ pk_prep_sc_kernel(const float* __restrict__ w, int ldw, const float* __restrict_
 // depthwise weights per channel block: 72 taps [tap][8 channels] + 8 biases
 __global__ void __launch_bounds__(256)
 pk_prep_dw_kernel(const float* __restrict__ w, const float* __restrict__ bias, int C, int seg, int seg_pad, int Cb,
-                  float* __restrict__ out) {
+                  float* __restrict__ out, int flip) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= Cb * 80) return;
     const int cb = e / 80, r = e % 80, tap = r / 8, j = r % 8;
     const int ch = src_channel(cb * 8 + j, seg, seg_pad, C);
     float v = 0.f;
-    if (ch >= 0) v = tap < 9 ? w[ch * 9 + tap] : (bias != nullptr ? bias[ch] : 0.f);
+    if (ch >= 0) v = tap < 9 ? w[ch * 9 + (flip ? 8 - tap : tap)] : (bias != nullptr ? bias[ch] : 0.f);
     out[e] = v;
 }
 
@@ -129,8 +92,9 @@ int pk_prep_sc_launch(const float* w, int ldw, const float* gamma, const float* 
     RST_LAUNCH_CHECK();
     return RST_OK;
 }
-int pk_prep_dw_launch(const float* w, const float* bias, int C, int seg, int seg_pad, int Cb, float* out, hipStream_t stream) {
-    hipLaunchKernelGGL(pk_prep_dw_kernel, dim3((unsigned)cdiv(Cb * 80, 256)), dim3(256), 0, stream, w, bias, C, seg, seg_pad, Cb, out);
+int pk_prep_dw_launch(const float* w, const float* bias, int C, int seg, int seg_pad, int Cb, float* out, hipStream_t stream,
+                      int flip) {
+    hipLaunchKernelGGL(pk_prep_dw_kernel, dim3((unsigned)cdiv(Cb * 80, 256)), dim3(256), 0, stream, w, bias, C, seg, seg_pad, Cb, out, flip);
     RST_LAUNCH_CHECK();
     return RST_OK;
 }

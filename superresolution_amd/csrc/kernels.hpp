@@ -186,7 +186,9 @@ int pk_prep_a_launch(const float* w, int64_t w_bs, int ldw, const float* gamma, 
                      int ntiles, int KS, bf16_t* frag, int64_t frag_bs, int nb, hipStream_t stream);
 int pk_prep_sc_launch(const float* w, int ldw, const float* gamma, const float* beta, const float* bias, int M, int K,
                       int seg, int seg_pad, int npos, float* s, float* c, hipStream_t stream);
-int pk_prep_dw_launch(const float* w, const float* bias, int C, int seg, int seg_pad, int Cb, float* out, hipStream_t stream);
+// flip: the taps rotated by 180 degrees (the data gradient of the convolution)
+int pk_prep_dw_launch(const float* w, const float* bias, int C, int seg, int seg_pad, int Cb, float* out, hipStream_t stream,
+                      int flip = 0);
 // depthwise 3x3 over `Cb` channel blocks.  gate: every block holds 4 channels of x1 and the same 4 of x2 (segments
 // interleaved by the weight preparation, seg_pad < 0); y[4 cb + i] = gelu(d[i]) * d[4 + i], y has Cb / 2 blocks
 struct DwPk {
@@ -223,6 +225,54 @@ int gram_pk_launch(GramPk g, hipStream_t stream);
 int pk_pack_launch(const void* src, int src_is_fp32, bf16_t* dst, int B, int C, int64_t N, hipStream_t stream);
 int pk_unpack_launch(const bf16_t* src, void* dst, int dst_is_fp32, int B, int C, int64_t N, hipStream_t stream);
 // packed <-> channels-last bf16 [B][H][W][C]; mode 1 / 2: through PixelUnshuffle(2) / PixelShuffle(2)
+
+// ---- bf16_bwd.hip: gradients on the packed layout ----
+// fragments of A[pos][kpos] = W^(T)[channel(pos)][channel(kpos0 + kpos)], kpos < Krange: rows and contraction index
+// both through the position -> channel map of a segmented packed buffer (seg / seg_pad as for pk_prep_a_launch)
+int pk_prep_at_launch(const float* w, int64_t w_bs, int ldw, int transA, int M, int mseg, int mseg_pad, int Ksrc, int kseg,
+                      int kseg_pad, int kpos0, int Krange, int ntiles, int KS, bf16_t* frag, int64_t frag_bs, int nb,
+                      hipStream_t stream);
+struct PrepAtJob {
+    const float* w; int ldw, transA, M, mseg, mseg_pad, Ksrc, kseg, kseg_pad, kpos0, Krange, ntiles, KS;
+    bf16_t* frag;
+};
+struct PrepAtJobs { int n; PrepAtJob job[8]; };
+int pk_prep_at_jobs_launch(const PrepAtJobs& jobs, hipStream_t stream);
+// partial[b][split] = [Ab*8][Bb*8] sums over the split's pixels of A[b][m][px] Bm[b][k][px], followed (with_rowsum) by
+// the Ab*8 sums of A's rows.  T, nsa, nsb, splits, chunk_px come from wgrad_pk_plan (needs Ab, Bb, B, N).
+struct WgradPk {
+    const bf16_t* A; int64_t a_bs; int Ab;
+    const bf16_t* Bm; int64_t b_bs; int Bb;
+    int B; int64_t N;
+    float* partial; int with_rowsum;
+    int T, nsa, nsb, splits; int64_t chunk_px;
+};
+void wgrad_pk_plan(WgradPk* g);
+size_t wgrad_pk_partial_floats(const WgradPk& g);
+int wgrad_pk_launch(const WgradPk& g, hipStream_t stream);
+// tap sums of a depthwise 3x3: red[Cb][80] = per channel block [9 taps][8] sums of dy[p] x[p + tap] and the 8 sums of dy
+struct DwWgradPk {
+    const bf16_t* dy; int64_t dy_bs; const bf16_t* x; int64_t x_bs;
+    int B, Cb, H, W;
+    float* partial;                      // dw_wgrad_pk_partial_floats
+    int rows;                            // filled by the launcher
+};
+size_t dw_wgrad_pk_partial_floats(int B, int Cb, int H, int W);
+int dw_wgrad_pk_launch(DwWgradPk a, float* red, hipStream_t stream);
+int dw_grad_unpack_launch(const float* red, float* dweight, float* dbias, int C, int seg, int seg_pad, int Cb, hipStream_t stream);
+// gelu(x1) * x2 on the interleaved layout (DwPk, gate) and its gradient; Gb = channel blocks of the product
+int gate_fwd_pk_launch(const bf16_t* d, bf16_t* g, int B, int Gb, int64_t N, hipStream_t stream);
+int gate_bwd_pk_launch(const bf16_t* dg, const bf16_t* d, bf16_t* dd, int B, int Gb, int64_t N, hipStream_t stream);
+// normalisation part of the channel LayerNorm, and dx = addend + its input gradient for dn = d/d(gamma xhat + beta)
+int ln_fwd_pk_launch(const bf16_t* x, bf16_t* y, int B, int Cb, int64_t N, int with_bias, hipStream_t stream);
+int ln_bwd_pk_launch(const bf16_t* dn, const bf16_t* x, const float* gamma, const bf16_t* addend, bf16_t* dx, int B, int Cb,
+                     int64_t N, int with_bias, hipStream_t stream);
+// y = W (gamma xhat + beta) + bias: parameter gradients from G[pos][c] = sum dy[pos] xhat[c] and S[pos] = sum dy[pos]
+int lnlin_grads_launch(const float* G, const float* S, const float* W, const float* gamma, const float* beta, float* dW,
+                       float* dbias, float* dgamma, float* dbeta, int M, int C, int seg, int seg_pad, hipStream_t stream);
+int crop2d_launch(const float* in, int ld_in, float* out, int rows, int cols, hipStream_t stream);
+int attn_bwd_mats_launch(const float* Eq, const float* Dq, const float* Dk, float* out, int B, int C, int c, hipStream_t stream);
+
 int pk_to_nhwc_launch(const bf16_t* src, bf16_t* dst, int B, int C, int64_t N, hipStream_t stream);
 int pk_from_nhwc_launch(const bf16_t* src, bf16_t* dst, int mode, int B, int C, int H, int W, hipStream_t stream);
 
