@@ -301,8 +301,8 @@ struct PkBwdBufs {
     bf16_t *dg, *dd, *du, *xh, *dn, *dx1, *dqkv, *dt;
     float *ghat, *nq, *nk;
     float *P, *Eq, *Dq, *Dk, *dGG, *dtemp_row, *dtemp_b, *dwo_b, *mats;
-    PkSliced wpoutT, wpinT, wqkvT;
-    PkWeight wmfT, wmat;
+    PkSliced wpoutT, wpinT, wqkvT, wmat;
+    PkWeight wmfT;
     float *dw_qkv_flip, *dw_ffn_flip;
     float *part, *red, *dw_part, *dw_red;          // red: [M][K] sums, then M row sums
     size_t part_floats, dw_floats;
@@ -337,7 +337,7 @@ void pk_bwd_carve(const rst_block_desc* d, Carve& cv, PkBwdBufs& b) {
     b.wpinT = pk_sliced_shape(C, 2 * Hp);     pk_sliced_carve(b.wpinT, cv, 1);
     b.wqkvT = pk_sliced_shape(C, 3 * C);      pk_sliced_carve(b.wqkvT, cv, 1);
     b.wmfT = pk_plain_weight(C, C);           b.wmfT.frag = cv.halves(b.wmfT.frag_elems() * B);
-    b.wmat = pk_plain_weight(C, C);           b.wmat.frag = cv.halves(b.wmat.frag_elems() * 4 * B);
+    b.wmat = pk_sliced_shape(2 * C, 2 * C);   pk_sliced_carve(b.wmat, cv, B);
     b.dw_qkv_flip = cv.floats((size_t)(3 * C / 8) * 80);
     b.dw_ffn_flip = cv.floats((size_t)(2 * Hp / 8) * 80);
     // the widest of the products over the pixels
@@ -416,11 +416,16 @@ static int pk_block_bwd(const rst_block_desc* d, const rst_block_params* p, cons
         g.Q = b.qkv; g.Kx = b.qkv + cn; g.bs = 3 * cn; g.cb = c / 8; g.heads = heads; g.B = B; g.N = N;
         g.splits = b.f.splits; g.chunk_px = b.f.chunk; g.partial = b.f.gram_part; g.sqq = b.f.sqq_part; g.sqk = b.f.sqk_part;
         RST_TRY(gram_pk_launch(g, stream));
-        RST_TRY(reduce_slabs_launch(b.f.gram_part, b.f.gram_red, (int64_t)c * c, B * heads, b.f.splits, 0, stream));
-        RST_TRY(reduce_slabs_launch(b.f.sqq_part, b.f.sqq_red, c, B * heads, b.f.splits, 0, stream));
-        RST_TRY(reduce_slabs_launch(b.f.sqk_part, b.f.sqk_red, c, B * heads, b.f.splits, 0, stream));
-        RST_TRY(attn_softmax_launch(b.f.gram_red, b.f.sqq_red, b.f.sqk_red, p->temperature, b.f.attn, b.ghat, b.nq, b.nk,
-                                    B, heads, c, 1, stream));
+        if (b.f.splits > 16) {
+            RST_TRY(reduce_slabs_launch(b.f.gram_part, b.f.gram_red, (int64_t)c * c, B * heads, b.f.splits, 0, stream));
+            RST_TRY(reduce_slabs_launch(b.f.sqq_part, b.f.sqq_red, c, B * heads, b.f.splits, 0, stream));
+            RST_TRY(reduce_slabs_launch(b.f.sqk_part, b.f.sqk_red, c, B * heads, b.f.splits, 0, stream));
+            RST_TRY(attn_softmax_launch(b.f.gram_red, b.f.sqq_red, b.f.sqk_red, p->temperature, b.f.attn, b.ghat, b.nq, b.nk,
+                                        B, heads, c, 1, stream));
+        } else {
+            RST_TRY(attn_softmax_launch(b.f.gram_part, b.f.sqq_part, b.f.sqk_part, p->temperature, b.f.attn, b.ghat, b.nq, b.nk,
+                                        B, heads, c, b.f.splits, stream));
+        }
         RST_TRY(attn_fold_launch(p->proj_weight, b.f.attn, b.f.mfold, B, C, heads, c, stream));
         RST_TRY(pk_prep_a_launch(b.f.mfold, (int64_t)C * C, C, nullptr, C, C, NOSEG, NOSEG, b.f.wattn.ntiles, b.f.wattn.KS, b.f.wattn.frag,
                                  (int64_t)b.f.wattn.frag_elems(), B, stream));
@@ -501,18 +506,18 @@ static int pk_block_bwd(const rst_block_desc* d, const rst_block_params* p, cons
     RST_TRY(reduce_slabs_launch(b.dwo_b, gr->proj_weight, (int64_t)C * C, 1, B, 0, stream));
     RST_TRY(reduce_slabs_launch(b.dtemp_b, gr->temperature, heads, 1, B, 0, stream));
     RST_TRY(attn_bwd_mats_launch(b.Eq, b.Dq, b.Dk, b.mats, B, C, c, stream));
-    const int64_t fe = (int64_t)b.wmat.frag_elems();
-    RST_TRY(pk_prep_a_launch(b.mats, (int64_t)C * C, C, nullptr, C, C, NOSEG, NOSEG, b.wmat.ntiles, b.wmat.KS, b.wmat.frag, fe, 4 * B, stream));
+    for (int i = 0; i < b.wmat.nslices; ++i)
+        RST_TRY(pk_prep_at_launch(b.mats, (int64_t)4 * C * C, 2 * C, 0, 2 * C, NOSEG, NOSEG, 2 * C, NOSEG, NOSEG, b.wmat.kpos0[i],
+                                  b.wmat.krange[i], b.wmat.w[i].ntiles, b.wmat.w[i].KS, b.wmat.w[i].frag,
+                                  (int64_t)b.wmat.w[i].frag_elems(), B, stream));
     RST_TRY(pk_prep_at_launch(b.f.mfold, (int64_t)C * C, C, 1, C, NOSEG, NOSEG, C, NOSEG, NOSEG, 0, C, b.wmfT.ntiles, b.wmfT.KS,
                               b.wmfT.frag, (int64_t)b.wmfT.frag_elems(), B, stream));
     {
-        // dq = BD(Eq) k + diag(Dq) q;  dk = BD(Eq)^T q + diag(Dk) k;  dv = M^T dx1
-        const bf16_t* src[4] = {k, q, q, k};
-        for (int j = 0; j < 4; ++j) {
-            bf16_t* out = b.dqkv + (j / 2) * cn;
-            GemmPk g = pk_gemm_args(b.wmat, src[j], 3 * cn, out, 3 * cn, B, N);
-            g.A = b.wmat.frag + (int64_t)j * fe; g.a_bs = 4 * fe / 8;
-            if (j & 1) { g.R = out; g.r_bs = 3 * cn; }
+        // [dq; dk] = A_b [q; k] (q and k are the first 2C channels of qkv);  dv = M^T dx1
+        for (int i = 0; i < b.wmat.nslices; ++i) {
+            GemmPk g = pk_gemm_args(b.wmat.w[i], b.qkv + (int64_t)(b.wmat.kpos0[i] / 8) * N * 8, 3 * cn, b.dqkv, 3 * cn, B, N);
+            g.a_bs = (int64_t)b.wmat.w[i].frag_elems() / 8;
+            if (i > 0) { g.R = b.dqkv; g.r_bs = 3 * cn; }
             RST_TRY(gemm_pk_launch(g, stream));
         }
         GemmPk g = pk_gemm_args(b.wmfT, b.dx1, cn, b.dqkv + 2 * cn, 3 * cn, B, N);

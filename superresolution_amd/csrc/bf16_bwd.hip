@@ -596,20 +596,25 @@ int crop2d_launch(const float* in, int ld_in, float* out, int rows, int cols, hi
     return RST_OK;
 }
 
-// The four C x C matrices per sample of the attention's q / k gradients, dq = BD(Eq) k + diag(Dq) q and
-// dk = BD(Eq)^T q + diag(Dk) k (BD: block diagonal over the heads): out[b][0..3][C][C]
+// The 2C x 2C matrix per sample of the attention's q / k gradients,
+//   [dq; dk] = [[diag(Dq), BD(Eq)], [BD(Eq)^T, diag(Dk)]] [q; k]      (BD: block diagonal over the heads)
 __global__ void __launch_bounds__(256)
 attn_bwd_mats_kernel(const float* __restrict__ Eq, const float* __restrict__ Dq, const float* __restrict__ Dk,
                      float* __restrict__ out, int B, int C, int c) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t cc = (int64_t)C * C;
-    if (e >= (int64_t)B * 4 * cc) return;
-    const int col = (int)(e % C), row = (int)((e / C) % C), j = (int)((e / cc) % 4), b = (int)(e / (4 * cc));
-    const int heads = C / c, hr = row / c, hc = col / c;
+    const int C2 = 2 * C;
+    const int64_t cc = (int64_t)C2 * C2;
+    if (e >= (int64_t)B * cc) return;
+    const int col = (int)(e % C2), row = (int)((e / C2) % C2), b = (int)(e / cc);
+    const int heads = C / c;
+    const int r = row % C, k = col % C, hr = r / c, hk = k / c;
+    const bool lower = row >= C, right = col >= C;
     float v = 0.f;
-    if (j == 0) { if (hr == hc) v = Eq[(((int64_t)b * heads + hr) * c + row % c) * c + col % c]; }
-    else if (j == 2) { if (hr == hc) v = Eq[(((int64_t)b * heads + hr) * c + col % c) * c + row % c]; }
-    else if (row == col) v = (j == 1 ? Dq : Dk)[(int64_t)b * C + row];
+    if (lower == right) { if (r == k) v = (lower ? Dk : Dq)[(int64_t)b * C + r]; }
+    else if (hr == hk) {
+        const float* E = Eq + ((int64_t)b * heads + hr) * c * c;
+        v = lower ? E[(k % c) * c + r % c] : E[(r % c) * c + k % c];
+    }
     out[e] = v;
 }
 int attn_bwd_mats_launch(const float* Eq, const float* Dq, const float* Dk, float* out, int B, int C, int c, hipStream_t stream) {

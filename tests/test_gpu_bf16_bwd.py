@@ -43,9 +43,9 @@ def test_block_backward_vs_fp32_kernels(C, heads, hidden, H, W, ln_bias, conv_bi
     dxp, g = bf16.block_backward(bf16.pack(x), bf16.pack(dy), heads, hidden, params)
     dx = bf16.unpack(dxp, torch.float32)
     assert torch.isfinite(dx).all()
-    assert _cos(dx, dx_ref) > 0.999, _cos(dx, dx_ref)                         # measured >= 0.9998
+    assert _cos(dx, dx_ref) > 0.999, _cos(dx, dx_ref)                         # measured 0.999997
     rel = float((dx - dx_ref).norm() / dx_ref.norm())
-    assert rel < 3e-2, rel                                                    # measured <= 1.2e-2
+    assert rel < 3e-2, rel                                                    # measured 2.4e-3 (the output's own rounding)
     for name, ref in g_ref.items():
         if ref is None:
             assert g[name] is None
@@ -56,7 +56,7 @@ def test_block_backward_vs_fp32_kernels(C, heads, hidden, H, W, ln_bias, conv_bi
             continue
         c = _cos(got, ref)
         r = float((got - ref).norm() / ref.norm())
-        assert c > 0.995 and r < 0.1, (name, c, r)                            # measured cos >= 0.9995, rel <= 3e-2
+        assert c > 0.995 and r < 0.1, (name, c, r)                            # measured cos >= 0.99998; rel <= 6e-3, temperature 2.9e-2
 
 
 def test_stage_backward_routes():
