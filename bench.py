@@ -331,6 +331,24 @@ def main():
                                "ms_per_step": round(el / args.steps * 1e3, 3), "dtype": "bf16",
                                "note": "same workload, activations stored in bf16 between kernels, fp32 sums and parameters; "
                                        "PSNR within 0.01 dB of the fp32 result (tests/test_gpu_bf16.py)"}
+        if rank == 0:
+            # kernels of the training path that the inference workload does not launch, at a headline shape:
+            # channel LayerNorm forward and backward (model/Restromer.py:26-52) at 16 x 96 x 256 x 256
+            from superresolution_amd import ops
+            xl = torch.randn(16, 96, 256, 256, device=dev).requires_grad_(True)
+            wl = torch.rand(96, device=dev).add_(0.5).requires_grad_(True)
+            bl = torch.randn(96, device=dev).requires_grad_(True)
+            gl = torch.randn(16, 96, 256, 256, device=dev)
+
+            def ln_step():
+                xl.grad = wl.grad = bl.grad = None
+                ops.layernorm(xl, wl, bl).backward(gl)
+            ln_step()
+            pl = kernel_profile(ln_step)
+            out["side_kernels"] = {"shape": "16x96x256x256 fp32, WithBias",
+                                   **{n: {"us": round(v["ms"] * 1e3, 1), "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)}
+                                      for n, v in pl.items()}}
+            del xl, gl
     if rank != 0 and args.mode in ("train", "tiled", "frame_sharded"):
         step()          # the profiled extra step on rank 0 contains collectives: every rank takes part
     if rank == 0:
