@@ -8,10 +8,17 @@
 //     chunk][dx][hi, lo] (conv3x3_f16s_prep);
 //   * a block owns 32 RT output channels x 128 pixels (TH rows x TW columns of one sample, TW = min(W, 128)).  Per
 //     (dy, channel chunk) ONE slab of the input -- 32 channels x 128 pixels of the rows shifted by dy, plus the four
-//     pixels either side when the image is wider than the tile -- comes in by LDS-DMA together with the weight
-//     fragments of its three horizontal taps; the three dx shifts are taken while reading the slab out of LDS
-//     (neighbouring column, halo column at the tile edge, zero outside the image), and converted on the way;
-//   * 2-deep ring: [everyone done with slab s-1] -> issue slab s+1 -> wait for slab s -> barrier -> multiply slab s.
+//     pixels either side when the image is wider than the tile -- comes in by LDS-DMA, and the weight fragments of its
+//     three horizontal taps likewise;
+//   * a landed slab is converted ONCE, by all eight waves together, into an operand image in LDS ([pixel slot][lane
+//     group] x 16 B, hi and lo; pixels outside the image become zeros there); the three horizontal taps are three reads
+//     of that image at slots shifted by one -- a tap costs two ds_read_b128 per 16 pixels instead of eight scalar reads
+//     and a conversion (8 convolutions of the network: 4.08 -> 3.28 ms);
+//   * one barrier per slab: [slab s+1 and the weights of slab s landed, image s complete, everyone done with slab s-1]
+//     -> issue slab s+2 and the weights of slab s+1 -> convert slab s+1 -> multiply slab s.  145 KB of LDS at RT = 3,
+//     one block per CU.  Measured at 96 -> 192 channels, 16 x 256 x 256: 1.44 ms = 720 TFLOP/s of f16 instructions,
+//     about a third of the matrix pipe's cycles; opposite conversion / multiplication order in the two waves of a SIMD
+//     and a third accumulator set (no back-to-back dependent instructions) changed nothing.
 // Epilogue through a wave-private LDS transpose: mode 0 plain NCHW rows, mode 1 PixelUnshuffle(2)
 // (out[4 m + 2 (y & 1) + (x & 1)][y / 2][x / 2]), mode 2 PixelShuffle(2) (out[m / 4][2 y + (m % 4) / 2][2 x + m % 2]).
 #include "kernels.hpp"
@@ -55,14 +62,18 @@ conv3x3_f16s_prep_kernel(const float* __restrict__ w, int Cout, int Cin, int kch
     out[64] = lo;
 }
 
+constexpr int C3_SLOTS = 136;                  // pixel slots of an operand image: TH rows x (TW + 2) columns, at most 4 x 34
+constexpr int C3_IMGH = C3_SLOTS * 4 * 4;      // floats of one half (hi or lo) of an image: [slot][lane group] x 16 B
+
 template <int RT>
 __global__ void __launch_bounds__(512)
 conv3x3_f16s_kernel(Conv3F a) {
     constexpr int AS = 3 * 2 * RT * 2 * 256;              // three taps x 2 RT tiles x (hi, lo) x 1 KiB
-    constexpr int STAGE = C3_XS + AS;
-    constexpr int NP = 17 + 12 * RT, P = (NP + 7) / 8;
+    constexpr int PW = (12 * RT + 7) / 8;                 // weight pieces per wave and slab
     extern __shared__ __attribute__((aligned(16))) float c3_ring[];
-    float* ring = c3_ring;                                // 2 stages + 256 floats for surplus pieces
+    float* xring = c3_ring;                               // [2][C3_XS] fp32 slabs as they land
+    float* wring = xring + 2 * C3_XS;                     // [2][AS] weight fragments
+    float* imgs = wring + 2 * AS;                         // [2][hi, lo][C3_IMGH] split-f16 operand images
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -79,71 +90,110 @@ conv3x3_f16s_kernel(Conv3F a) {
     const char* Af = static_cast<const char*>(a.afrag);
     const int NS = 3 * a.kch, NQ = 9 * a.kch;
 
-    // ---- DMA pieces of this wave: ids wave + 8 i; [0, 16) slab pieces of two channel rows, 16 the halo piece,
-    // then 12 RT weight pieces (tap, tile, hi/lo) ----
-    int kind[P], dsto[P], chrow[P], ysrc0[P], xsrc[P];
-    int64_t aoff[P];
-#pragma unroll
-    for (int i = 0; i < P; ++i) {
-        const int id = wave + 8 * i;
-        kind[i] = 3; dsto[i] = -1; chrow[i] = 0; ysrc0[i] = 0; xsrc[i] = 0; aoff[i] = 0;
-        if (id < 16) {
-            kind[i] = 0;
-            chrow[i] = 2 * id + (lane >> 5);
-            const int n = (lane & 31) * 4;
-            ysrc0[i] = y0 + n / TW; xsrc[i] = x0 + n % TW;
-            dsto[i] = id * C3_XPIECE;
-        } else if (id == 16) {
-            kind[i] = 1;
-            chrow[i] = lane >> 1;
-            int col = (lane & 1) ? x0 + TW : x0 - 4;
-            col = col < 0 ? 0 : (col > W - 4 ? W - 4 : col);      // outside the image: any valid address, masked when read
-            ysrc0[i] = y0; xsrc[i] = col;
-            dsto[i] = 16 * C3_XPIECE;
-        } else if (id < NP) {
-            kind[i] = 2;
-            const int j = id - 17, hl = j & 1, t = (j >> 1) % (2 * RT), dxi = j / (4 * RT);
-            int mt = m0 / 16 + t;
-            if (mt > a.mtiles - 1) mt = a.mtiles - 1;
-            aoff[i] = (((int64_t)mt * NQ + dxi) * 2 + hl) * 1024 + lane * 16;
-            dsto[i] = C3_XS + ((dxi * 2 * RT + t) * 2 + hl) * 256;
-        }
-    }
-    auto issue = [&](int s) __attribute__((always_inline)) {
-        float* st = ring + (s & 1) * STAGE;
+    // ---- DMA pieces of this wave: slab pieces 0..15 (two channel rows each), 16 the halo piece; weight pieces
+    // (tap, tile, hi/lo) of 1 KiB ----
+    auto issue_x = [&](int s) __attribute__((always_inline)) {
+        float* st = xring + (s & 1) * C3_XS;
         const int dy = s / a.kch - 1, kc = s % a.kch;
 #pragma unroll
-        for (int i = 0; i < P; ++i) {
-            float* dst = dsto[i] >= 0 ? st + dsto[i] : ring + 2 * STAGE;
-            const void* src;
-            if (kind[i] <= 1) {
-                int ch = 32 * kc + chrow[i];
-                if (ch > a.Cin - 1) ch = a.Cin - 1;                // channels past Cin meet zero weights
-                int ys = ysrc0[i] + dy;
-                ys = ys < 0 ? 0 : (ys > H - 1 ? H - 1 : ys);        // rows outside the image are masked when read
-                src = Xb + (int64_t)ch * HW + (int64_t)ys * W + xsrc[i];
+        for (int i = 0; i < 3; ++i) {
+            const int id = wave + 8 * i;
+            if (id > 16) break;
+            int chrow, ys, xs;
+            float* dst;
+            if (id < 16) {
+                chrow = 2 * id + (lane >> 5);
+                const int n = (lane & 31) * 4;
+                ys = y0 + n / TW + dy; xs = x0 + n % TW;
+                dst = st + id * C3_XPIECE;
             } else {
-                src = Af + aoff[i] + (int64_t)s * 3 * 2048;
+                chrow = lane >> 1;
+                int col = (lane & 1) ? x0 + TW : x0 - 4;
+                col = col < 0 ? 0 : (col > W - 4 ? W - 4 : col);      // outside the image: any valid address, zeroed when converted
+                ys = y0 + dy; xs = col;
+                dst = st + 16 * C3_XPIECE;
             }
+            int ch = 32 * kc + chrow;
+            if (ch > a.Cin - 1) ch = a.Cin - 1;                        // channels past Cin meet zero weights
+            ys = ys < 0 ? 0 : (ys > H - 1 ? H - 1 : ys);               // rows outside the image are zeroed when converted
+            const float* src = Xb + (int64_t)ch * HW + (int64_t)ys * W + xs;
+            __builtin_amdgcn_global_load_lds((c3_gptr)src, (c3_lptr)dst, 16, 0, 0);
+        }
+    };
+    auto issue_w = [&](int s) __attribute__((always_inline)) {
+        float* st = wring + (s & 1) * AS;
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int j = wave + 8 * i;
+            if (j >= 12 * RT) break;
+            const int hl = j & 1, t = (j >> 1) % (2 * RT), dxi = j / (4 * RT);
+            int mt = m0 / 16 + t;
+            if (mt > a.mtiles - 1) mt = a.mtiles - 1;
+            const char* src = Af + (((int64_t)mt * NQ + (int64_t)s * 3 + dxi) * 2 + hl) * 1024 + lane * 16;
+            float* dst = st + ((dxi * 2 * RT + t) * 2 + hl) * 256;
             __builtin_amdgcn_global_load_lds((c3_gptr)src, (c3_lptr)dst, 16, 0, 0);
         }
     };
 
-    // ---- this lane's two pixels (one per 16-pixel tile) and how a horizontal tap reaches its neighbour ----
-    int a0[2][3], sJ[2][3], sE[2][3];
-    bool vx[2][3], vy[2][3];
+    // ---- conversion: every lane turns the 8 channels of one (pixel, lane group) of a landed slab into the hi and lo
+    // chunks of the operand image, once per slab; the three horizontal taps then read the image at shifted slots.
+    // Pixels outside the image become zeros here.  Slot of tile pixel (ty, tx): ty (TW + 2) + tx + 1. ----
+    const int cn = wave * 16 + (lane >> 2), cg = lane & 3;             // this lane's pixel of the tile and lane group
+    const int cty = cn / TW, ctx = cn % TW;
+    const int cslot = cty * (TW + 2) + ctx + 1;
+    auto split_store = [&](const float* v, bool ok, float* im, int slot, int g) __attribute__((always_inline)) {
+        c3_h8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const c3_f32x2 vv = {ok ? v[2 * j] : 0.f, ok ? v[2 * j + 1] : 0.f};
+            const c3_h2 h = __builtin_convertvector(vv, c3_h2);
+            const c3_f32x2 sc = vv * 2048.f;
+            const c3_f32x2 r2 = {fmaf((float)h[0], -2048.f, sc[0]), fmaf((float)h[1], -2048.f, sc[1])};
+            const c3_h2 l = __builtin_convertvector(r2, c3_h2);
+            hi[2 * j] = h[0]; hi[2 * j + 1] = h[1];
+            lo[2 * j] = l[0]; lo[2 * j + 1] = l[1];
+        }
+        reinterpret_cast<c3_h8*>(im)[slot * 4 + g] = hi;
+        reinterpret_cast<c3_h8*>(im + C3_IMGH)[slot * 4 + g] = lo;
+    };
+    auto convert = [&](int s) __attribute__((always_inline)) {
+        const float* st = xring + (s & 1) * C3_XS;
+        float* im = imgs + (s & 1) * 2 * C3_IMGH;
+        const int dy = s / a.kch - 1;
+        {
+            float v[8];
+            const float* xs = st + cg * C3_XPIECE + cn;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[2 * j] = xs[4 * j * C3_XPIECE]; v[2 * j + 1] = xs[4 * j * C3_XPIECE + 128]; }
+            const int yy = y0 + cty + dy;
+            split_store(v, yy >= 0 && yy < H, im, cslot, cg);
+        }
+        if (TW == 128 && wave == 0 && lane < 8) {
+            // the two columns either side of a full-width tile (one tile row): halo piece [channel][side][4 px]
+            const int side = lane >> 2, g = lane & 3;
+            float v[8];
+            const float* hs = st + 16 * C3_XPIECE + (side ? 4 : 3);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[2 * j] = hs[(2 * g + 8 * j) * 8]; v[2 * j + 1] = hs[(2 * g + 8 * j + 1) * 8]; }
+            const int yy = y0 + dy, xx = side ? x0 + TW : x0 - 1;
+            split_store(v, yy >= 0 && yy < H && xx >= 0 && xx < W, im, side ? TW + 1 : 0, g);
+        }
+    };
+    if (TW < 128) {
+        // narrower images: a tile spans the width, the columns either side are outside the image -- zero, written once
+        for (int e = tid; e < 2 * a.TH * 4 * 4; e += 512) {
+            const int buf = e & 1, hl = (e >> 1) & 1, g = (e >> 2) & 3, r = e >> 4;      // r: (tile row, side)
+            const int slot = (r >> 1) * (TW + 2) + ((r & 1) ? TW + 1 : 0);
+            reinterpret_cast<c3_h8*>(imgs + (buf * 2 + hl) * C3_IMGH)[slot * 4 + g] = c3_h8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+
+    // slots of this lane's two pixels (one per 16-pixel tile) for the multiplication
+    int mslot[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int n = 32 * nq + 16 * t + lm;
-        const int ty = n / TW, tx = n % TW;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const int dx = d - 1, txs = tx + dx;
-            vx[t][d] = x0 + txs >= 0 && x0 + txs < W;
-            vy[t][d] = y0 + ty + d - 1 >= 0 && y0 + ty + d - 1 < H;
-            if (txs >= 0 && txs < TW) { a0[t][d] = kk * C3_XPIECE + n + dx; sJ[t][d] = 4 * C3_XPIECE; sE[t][d] = 128; }
-            else { a0[t][d] = 16 * C3_XPIECE + kk * 16 + (txs < 0 ? 3 : 4); sJ[t][d] = 64; sE[t][d] = 8; }
-        }
+        mslot[t] = (n / TW) * (TW + 2) + n % TW + 1;
     }
 
     f32x4 acc1[RT][2], acc2[RT][2];
@@ -161,61 +211,28 @@ conv3x3_f16s_kernel(Conv3F a) {
         acc2[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
-    issue(0);
+    // ---- pipeline: one barrier per slab.  Iteration s: [slab s + 1 and the weights of slab s have landed, image s is
+    // complete, everyone is done multiplying slab s - 1] -> issue slab s + 2 (into the stage slab s was converted out
+    // of) and the weights of slab s + 1 -> convert slab s + 1 -> multiply slab s ----
+    issue_x(0); issue_w(0);
+    if (NS > 1) issue_x(1);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+    convert(0);
     for (int s = 0; s < NS; ++s) {
-        // everyone is done with slab s - 1: its stage takes slab s + 1 (past the end: the last slab again, into the
-        // stage that is not being read -- keeps the count of pieces in flight fixed); then slab s has landed
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        {
-            const int sn = s + 1 < NS ? s + 1 : NS - 1;
-            float* keep = ring;     // (issue() picks the stage by parity of its argument: force the other stage)
-            (void)keep;
-            if (s + 1 < NS) issue(sn);
-            else {
-                // same pieces, other stage
-                float* st = ring + ((s + 1) & 1) * STAGE;
-                const int dy = sn / a.kch - 1, kc = sn % a.kch;
-#pragma unroll
-                for (int i = 0; i < P; ++i) {
-                    float* dst = dsto[i] >= 0 ? st + dsto[i] : ring + 2 * STAGE;
-                    const void* src;
-                    if (kind[i] <= 1) {
-                        int ch = 32 * kc + chrow[i];
-                        if (ch > a.Cin - 1) ch = a.Cin - 1;
-                        int ys = ysrc0[i] + dy;
-                        ys = ys < 0 ? 0 : (ys > H - 1 ? H - 1 : ys);
-                        src = Xb + (int64_t)ch * HW + (int64_t)ys * W + xsrc[i];
-                    } else {
-                        src = Af + aoff[i] + (int64_t)sn * 3 * 2048;
-                    }
-                    __builtin_amdgcn_global_load_lds((c3_gptr)src, (c3_lptr)dst, 16, 0, 0);
-                }
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(P) : "memory");
-        const float* st = ring + (s & 1) * STAGE;
-        const int dyi = s / a.kch;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (s + 2 < NS) issue_x(s + 2);
+        if (s + 1 < NS) { issue_w(s + 1); convert(s + 1); }
+        const float* im = imgs + (s & 1) * 2 * C3_IMGH;
+        const float* ws = wring + (s & 1) * AS;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
             c3_h8 xh[2], xl[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const bool ok = vx[t][d] && vy[t][dyi];
-                const float* xs = st + a0[t][d];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v0 = xs[j * sJ[t][d]], v1 = xs[j * sJ[t][d] + sE[t][d]];
-                    v0 = ok ? v0 : 0.f; v1 = ok ? v1 : 0.f;
-                    const c3_f32x2 vv = {v0, v1};
-                    const c3_h2 h = __builtin_convertvector(vv, c3_h2);
-                    const c3_f32x2 sc = vv * 2048.f;
-                    const c3_f32x2 r2 = {fmaf((float)h[0], -2048.f, sc[0]), fmaf((float)h[1], -2048.f, sc[1])};
-                    const c3_h2 l = __builtin_convertvector(r2, c3_h2);
-                    xh[t][2 * j] = h[0]; xh[t][2 * j + 1] = h[1];
-                    xl[t][2 * j] = l[0]; xl[t][2 * j + 1] = l[1];
-                }
+                xh[t] = reinterpret_cast<const c3_h8*>(im)[(mslot[t] + d - 1) * 4 + kk];
+                xl[t] = reinterpret_cast<const c3_h8*>(im + C3_IMGH)[(mslot[t] + d - 1) * 4 + kk];
             }
-            const c3_h8* af = reinterpret_cast<const c3_h8*>(st + C3_XS) + (d * 2 * RT + mh * RT) * 2 * 64 + lane;
+            const c3_h8* af = reinterpret_cast<const c3_h8*>(ws) + (d * 2 * RT + mh * RT) * 2 * 64 + lane;
 #pragma unroll
             for (int i = 0; i < RT; ++i) {
                 const c3_h8 ah = af[(i * 2 + 0) * 64], al = af[(i * 2 + 1) * 64];
@@ -228,6 +245,7 @@ conv3x3_f16s_kernel(Conv3F a) {
             }
         }
     }
+    float* ring = c3_ring;
 
     // ---- epilogue: the wave's 16 RT rows x 32 pixels (32 consecutive columns of ONE image row) ----
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the ring is free: reuse it
@@ -280,7 +298,7 @@ conv3x3_f16s_kernel(Conv3F a) {
 int c3_pick_rt(int M) {
     int best = 1;
     int64_t best_pad = INT64_MAX;
-    for (int rt = 4; rt >= 1; --rt) {
+    for (int rt = 3; rt >= 1; --rt) {          // 4 would need 171 KB of LDS
         const int64_t pad = cdiv(M, 32 * rt) * 32 * rt;
         if (pad < best_pad) { best_pad = pad; best = rt; }
     }
@@ -325,11 +343,10 @@ int conv3x3_f16s_launch(const float* x, const float* w, const float* bias, float
     RST_LAUNCH_CHECK();
     const int64_t gx = (int64_t)a.tiles_x * a.tiles_y * a.mblocks;
     RST_REQUIRE(gx < (1ll << 31), "conv3x3: grid too large");
-    const size_t lds = sizeof(float) * (size_t)(2 * (C3_XS + 3 * 2 * rt * 2 * 256) + 256);
+    const size_t lds = sizeof(float) * (size_t)(2 * (C3_XS + 3 * 2 * rt * 2 * 256) + 4 * C3_IMGH);
     const void* kern = rt == 1 ? reinterpret_cast<const void*>(&conv3x3_f16s_kernel<1>)
                      : rt == 2 ? reinterpret_cast<const void*>(&conv3x3_f16s_kernel<2>)
-                     : rt == 3 ? reinterpret_cast<const void*>(&conv3x3_f16s_kernel<3>)
-                               : reinterpret_cast<const void*>(&conv3x3_f16s_kernel<4>);
+                               : reinterpret_cast<const void*>(&conv3x3_f16s_kernel<3>);
     KernelSetup su;
     RST_TRY(kernel_setup(kern, 512, lds, &su));
     const double px = (double)B * H * W;
