@@ -246,6 +246,7 @@ class Restormer(nn.Module):
             cache = getattr(m, "_pk_cache", None)
             if cache is not None:
                 cache.invalidate()
+        self.__dict__.pop("_bf16_conv_weights", None)
 
     def _apply(self, fn, *args, **kwargs):
         # .to() / .float() / .cuda() may replace parameter storage behind the same version number
@@ -267,10 +268,18 @@ class Restormer(nn.Module):
 
         cl = torch.channels_last
 
+        wcache = self.__dict__.setdefault("_bf16_conv_weights", {})
+
         def conv3(x, conv):
-            # dense 3x3 through torch (MIOpen), channels-last on both sides so that no transposition runs around it
-            return F.conv2d(x, conv.weight.to(bf).contiguous(memory_format=cl), None if conv.bias is None else conv.bias.to(bf),
-                            padding=1)
+            # dense 3x3 through torch (MIOpen), channels-last on both sides so that no transposition runs around it;
+            # the bf16 channels-last copy of the weights is kept until the parameter is written again
+            key = (conv.weight.data_ptr(), conv.weight._version, None if conv.bias is None else conv.bias._version)
+            hit = wcache.get(id(conv))
+            if hit is None or hit[0] != key:
+                hit = (key, conv.weight.detach().to(bf).contiguous(memory_format=cl),
+                       None if conv.bias is None else conv.bias.detach().to(bf))
+                wcache[id(conv)] = hit
+            return F.conv2d(x, hit[1], hit[2], padding=1)
 
         def stage(p, blocks):
             for blk in blocks:

@@ -120,8 +120,14 @@ class DataParallelTrainer:
         dev, dt = params[0].device, params[0].dtype
         use_fused = dev.type == "cuda"
         self.optimizer = torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, fused=use_fused)
-        # buckets in reverse registration order
+        self.reduce = self.comm.active(self.world)
         self.buckets: List[_Bucket] = []
+        self._owner = {}
+        if not self.reduce:
+            # one rank, nothing to reduce: no communication buffers; gradients are dropped (not zeroed) between steps,
+            # so autograd keeps each produced gradient as it is instead of adding it to a zero
+            return
+        # buckets in reverse registration order
         cap = int(bucket_mb * 1e6 / params[0].element_size())
         cur: List[nn.Parameter] = []
         n = 0
@@ -133,15 +139,12 @@ class DataParallelTrainer:
                 cur, n = [], 0
         if cur:
             self.buckets.append(_Bucket(cur, dev, dt))
-        self._owner = {}
         for b in self.buckets:
             for i, (p, v) in enumerate(zip(b.params, b.views)):
                 p.grad = v
                 self._owner[p] = (b, i)
-        self.reduce = self.comm.active(self.world)
-        if self.reduce:
-            for p in params:
-                p.register_post_accumulate_grad_hook(self._on_grad_ready)
+        for p in params:
+            p.register_post_accumulate_grad_hook(self._on_grad_ready)
         self.broadcast_parameters()
 
     def broadcast_parameters(self):
@@ -170,6 +173,10 @@ class DataParallelTrainer:
             b.handle = self.comm.all_reduce(b.flat, async_op=True)
 
     def zero_grad(self):
+        if not self.reduce:
+            for p in self.params:
+                p.grad = None
+            return
         for b in self.buckets:
             b.flat.zero_()
             b.pending = len(b.params)
