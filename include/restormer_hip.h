@@ -331,6 +331,18 @@ int rst_bf16_conv1x1_fwd(const void* x_packed, const float* weight, const float*
                          const void* residual_packed, void* y_packed,
                          int32_t B, int32_t Cin, int32_t Cout, int64_t N,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* OverlapPatchEmbed.proj, Downsample, Upsample (model/Restromer.py:172-215) on   */
+/* packed tensors: nn.Conv2d(Cin, Cout, 3, padding=1) followed by nothing          */
+/* (shuffle_mode 0; Cout % 8 == 0), nn.PixelUnshuffle(2) (1: y packed 4 Cout       */
+/* channels at H/2 x W/2; H, W, Cout even) or nn.PixelShuffle(2) (2: y packed       */
+/* Cout / 4 channels at 2H x 2W; Cout % 32 == 0).  x: packed Cin channels (the      */
+/* padding channels of its last block must be zero, as rst_bf16_pack writes them).  */
+/* weight / bias fp32.                                                              */
+size_t rst_bf16_conv3x3_workspace_bytes(int32_t Cin, int32_t Cout);
+int32_t rst_bf16_conv3x3_supported(int32_t Cin, int32_t Cout, int32_t H, int32_t W, int32_t shuffle_mode);
+int rst_bf16_conv3x3_fwd(const void* x_packed, const float* weight, const float* bias, void* y_packed,
+                         int32_t B, int32_t Cin, int32_t Cout, int32_t H, int32_t W, int32_t shuffle_mode,
+                         void* workspace, size_t workspace_bytes, void* stream);
 /* TransformerBlock.forward, model/Restromer.py:163-167, on a packed tensor;      */
 /* y may alias x.  C % 8 == 0, C / heads a multiple of 16 (<= 192), C and hidden  */
 /* at most 480, W even.  Returns 0 bytes / RST_ERR_INVALID for unsupported shapes. */

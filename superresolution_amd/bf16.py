@@ -122,6 +122,30 @@ def conv1x1(p: Packed, weight: torch.Tensor, bias: Optional[torch.Tensor] = None
     return Packed(out, Cout)
 
 
+def conv3x3_supported(Cin: int, Cout: int, H: int, W: int, mode: int) -> bool:
+    return bool(_lib.load().rst_bf16_conv3x3_supported(Cin, Cout, H, W, mode))
+
+
+def conv3x3(p: Packed, weight: torch.Tensor, bias: Optional[torch.Tensor], mode: int = 0) -> Packed:
+    """nn.Conv2d(Cin, Cout, 3, padding=1) on a packed tensor, followed by nothing (mode 0), nn.PixelUnshuffle(2)
+    (mode 1) or nn.PixelShuffle(2) (mode 2) -- OverlapPatchEmbed / Downsample / Upsample of the reference
+    (model/Restromer.py:172-215) in one kernel (rst_bf16_conv3x3_fwd)."""
+    lib = _lib.load()
+    B, Cin, H, W = p.shape
+    w, b = _f32(weight, "conv3x3 weight"), _f32(bias, "conv3x3 bias")
+    Cout = w.shape[0]
+    if tuple(w.shape) != (Cout, Cin, 3, 3):
+        raise RuntimeError(f"conv3x3: weight {tuple(w.shape)} does not fit {Cin} input channels")
+    if not lib.rst_bf16_conv3x3_supported(Cin, Cout, H, W, mode):
+        raise RuntimeError(f"conv3x3: shape Cin={Cin} Cout={Cout} {H}x{W} mode={mode} not supported by the bf16 path")
+    Co, Ho, Wo = (Cout, H, W) if mode == 0 else (4 * Cout, H // 2, W // 2) if mode == 1 else (Cout // 4, 2 * H, 2 * W)
+    out = torch.empty((B, (Co + 7) // 8, Ho, Wo, 8), dtype=torch.bfloat16, device=p.data.device)
+    ws = workspace(lib.rst_bf16_conv3x3_workspace_bytes(Cin, Cout), p.data.device)
+    check(lib.rst_bf16_conv3x3_fwd(_ptr(p.data), _ptr(w), _ptr(b), _ptr(out), B, Cin, Cout, H, W, mode, _ptr(ws), ws.numel(),
+                                   _stream()), "rst_bf16_conv3x3_fwd")
+    return Packed(out, Co)
+
+
 class PreparedCache:
     """Prepared weights of one block (rst_bf16_block_prepare), rebuilt when a parameter tensor is replaced or
     modified in place (torch bumps ``_version`` on every in-place write, including optimizer steps, ``copy_`` and

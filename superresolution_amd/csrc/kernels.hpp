@@ -273,6 +273,12 @@ int lnlin_grads_launch(const float* G, const float* S, const float* W, const flo
 int crop2d_launch(const float* in, int ld_in, float* out, int rows, int cols, hipStream_t stream);
 int attn_bwd_mats_launch(const float* Eq, const float* Dq, const float* Dk, float* out, int B, int C, int c, hipStream_t stream);
 
+// ---- conv3x3_pk.hip: dense 3x3 convolution on packed tensors; mode 1 / 2: PixelUnshuffle(2) / PixelShuffle(2) epilogue ----
+bool conv3x3_pk_supported(int Cin, int Cout, int H, int W, int mode);
+size_t conv3x3_pk_ws_bytes(int Cin, int Cout);
+int conv3x3_pk_launch(const bf16_t* x, const float* w, const float* bias, bf16_t* y, int B, int Cin, int Cout, int H, int W,
+                      int mode, void* ws, size_t ws_bytes, hipStream_t stream);
+
 int pk_to_nhwc_launch(const bf16_t* src, bf16_t* dst, int B, int C, int64_t N, hipStream_t stream);
 int pk_from_nhwc_launch(const bf16_t* src, bf16_t* dst, int mode, int B, int C, int H, int W, hipStream_t stream);
 

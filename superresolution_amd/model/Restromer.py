@@ -246,7 +246,6 @@ class Restormer(nn.Module):
             cache = getattr(m, "_pk_cache", None)
             if cache is not None:
                 cache.invalidate()
-        self.__dict__.pop("_bf16_conv_weights", None)
 
     def _apply(self, fn, *args, **kwargs):
         # .to() / .float() / .cuda() may replace parameter storage behind the same version number
@@ -257,29 +256,25 @@ class Restormer(nn.Module):
 
     def _forward_bf16(self, inp_img):
         """Inference with bf16 activations (a bf16 input, or an fp32 input under bf16 autocast): every
-        TransformerBlock and 1x1 convolution runs on the library's channel-packed bf16 tensors with fp32 sums
-        and fp32 parameters, PixelUnshuffle / PixelShuffle happen inside the library's layout conversions; the dense
-        3x3 convolutions run in bf16 through torch (channels-last), the last layer and the bilinear residual in
-        fp32.  The result has the input's dtype."""
+        TransformerBlock, 1x1 convolution and dense 3x3 convolution (PixelUnshuffle / PixelShuffle as its epilogue)
+        runs on the library's channel-packed bf16 tensors with fp32 sums and fp32 parameters; the last layer and the
+        bilinear residual run in fp32.  The result has the input's dtype."""
         from .. import bf16 as pk
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             raise RuntimeError("the bf16 path is inference only: call it under torch.no_grad()")
-        bf = torch.bfloat16
 
-        cl = torch.channels_last
+        import os
+        via_torch = os.environ.get("RST_BF16_CONV") == "torch"
 
-        wcache = self.__dict__.setdefault("_bf16_conv_weights", {})
-
-        def conv3(x, conv):
-            # dense 3x3 through torch (MIOpen), channels-last on both sides so that no transposition runs around it;
-            # the bf16 channels-last copy of the weights is kept until the parameter is written again
-            key = (conv.weight.data_ptr(), conv.weight._version, None if conv.bias is None else conv.bias._version)
-            hit = wcache.get(id(conv))
-            if hit is None or hit[0] != key:
-                hit = (key, conv.weight.detach().to(bf).contiguous(memory_format=cl),
-                       None if conv.bias is None else conv.bias.detach().to(bf))
-                wcache[id(conv)] = hit
-            return F.conv2d(x, hit[1], hit[2], padding=1)
+        def conv3(p, conv, mode):
+            if via_torch:
+                # A/B aid: the convolution through torch (MIOpen) in bf16, channels-last, shuffle in the layout conversion
+                bf, cl = torch.bfloat16, torch.channels_last
+                src = pk.to_channels_last(p) if p.C % 8 == 0 else pk.unpack(p).contiguous(memory_format=cl)
+                y = F.conv2d(src, conv.weight.detach().to(bf).contiguous(memory_format=cl),
+                             None if conv.bias is None else conv.bias.detach().to(bf), padding=1)
+                return pk.from_channels_last(y, mode)
+            return pk.conv3x3(p, conv.weight, conv.bias, mode)
 
         def stage(p, blocks):
             for blk in blocks:
@@ -288,16 +283,16 @@ class Restormer(nn.Module):
                 pk.block_(p, blk.attn.num_heads, blk.ffn.hidden_features, blk._params(), blk._pk_cache)
             return p
 
-        def down(p, mod):        # conv3x3 then PixelUnshuffle(2), the shuffle inside the layout conversion
-            return pk.from_channels_last(conv3(pk.to_channels_last(p), mod.body[0]), 1)
+        def down(p, mod):        # conv3x3 then PixelUnshuffle(2)
+            return conv3(p, mod.body[0], 1)
 
         def up(p, mod):          # conv3x3 then PixelShuffle(2)
-            return pk.from_channels_last(conv3(pk.to_channels_last(p), mod.body[0]), 2)
+            return conv3(p, mod.body[0], 2)
 
-        e1_in = pk.from_channels_last(conv3(inp_img.to(bf).contiguous(memory_format=cl), self.patch_embed.proj), 0)
+        e1_in = conv3(pk.pack(inp_img), self.patch_embed.proj, 0)
         skip = None
         if self.dual_pixel_task:
-            skip = pk.unpack(pk.conv1x1(e1_in, self.skip_conv.weight, self.skip_conv.bias))
+            skip = pk.unpack(pk.conv1x1(e1_in, self.skip_conv.weight, self.skip_conv.bias), torch.float32)
         e1 = stage(e1_in, self.encoder_level1)                       # in place: e1_in is consumed
         e2 = stage(down(e1, self.down1_2), self.encoder_level2)
         e3 = stage(down(e2, self.down2_3), self.encoder_level3)
@@ -307,16 +302,16 @@ class Restormer(nn.Module):
         d2 = pk.conv1x1(pk.cat(up(d3, self.up3_2), e2), self.reduce_chan_level2.weight, self.reduce_chan_level2.bias)
         d2 = stage(d2, self.decoder_level2)
         d1 = stage(stage(pk.cat(up(d2, self.up2_1), e1), self.decoder_level1), self.refinement)
-        upx = F.pixel_shuffle(conv3(pk.to_channels_last(d1), self.output_upscale.body[0]), 2)
+        upx = pk.unpack(up(d1, self.output_upscale), torch.float32)
         if self.dual_pixel_task:
-            out = conv3(upx + skip, self.output).float().contiguous()
+            out = self.output(upx + skip)
         else:
             base = F.interpolate(inp_img.float(), scale_factor=2, mode="bilinear", align_corners=False)
             if self.output.weight.shape[0] <= 4:
                 bias = None if self.output.bias is None else self.output.bias.float()
-                out = ops.conv3x3_fewout(upx.to(dtype=torch.float32, memory_format=torch.contiguous_format), self.output.weight.float(), bias, base)
+                out = ops.conv3x3_fewout(upx, self.output.weight.float(), bias, base)
             else:
-                out = conv3(upx, self.output).float().contiguous() + base
+                out = self.output(upx) + base
         return out.to(inp_img.dtype)
 
     def forward(self, inp_img):
@@ -397,6 +392,9 @@ class Restormer(nn.Module):
                                          blk.norm1.body.with_bias, blk.attn.qkv.bias is not None)
                     ok = ok and c % 8 == 0 and lib.rst_bf16_block_workspace_bytes(ctypes.byref(desc)) != 0
             ok = ok and lib.rst_bf16_conv1x1_workspace_bytes(self.reduce_chan_level3.in_channels, self.reduce_chan_level3.out_channels) != 0
+            for conv, mode in ((self.patch_embed.proj, 0), (self.down1_2.body[0], 1), (self.down2_3.body[0], 1), (self.down3_4.body[0], 1),
+                               (self.up4_3.body[0], 2), (self.up3_2.body[0], 2), (self.up2_1.body[0], 2), (self.output_upscale.body[0], 2)):
+                ok = ok and bool(lib.rst_bf16_conv3x3_supported(conv.in_channels, conv.out_channels, 16, 16, mode))
             self._bf16_widths_ok = bool(ok)
         return ok
 

@@ -80,6 +80,9 @@ def test_bf16_frame_many_gram_splits_vs_oracle(frame):
         y = net(x.cuda().bfloat16()).double().cpu()
         with torch.autocast("cuda", dtype=torch.bfloat16):
             y_ac = net(x.cuda()).double().cpu()
-    for o in (y, y_ac):
+    # A bf16 result carries the rounding of its own container (rms 1.0e-3 on values in [0.25, 1), as much as the whole
+    # network adds: 0.98e-3), whatever computed it: the bf16-in / bf16-out call is held against the oracle's output in
+    # the same container, the autocast call (fp32 result) against the oracle's output as it is.
+    for o, r in ((y, ref.bfloat16().double()), (y_ac, ref)):
         assert float((o - ref).abs().max() / ref.abs().max()) < BF16_TOL
-        assert abs(_psnr(o, target) - _psnr(ref, target)) < 0.01, (_psnr(o, target), _psnr(ref, target))
+        assert abs(_psnr(o, target) - _psnr(r, target)) < 0.01, (_psnr(o, target), _psnr(r, target))
