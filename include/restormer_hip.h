@@ -263,6 +263,16 @@ size_t rst_block_saved_bytes(const rst_block_desc* desc);
 int rst_block_fwd(const rst_block_desc* desc, const rst_block_params* params,
                   const float* x, float* y,
                   void* saved, void* workspace, size_t workspace_bytes, void* stream);
+/* Inference with the input-independent part done ahead: rst_block_prepare writes  */
+/* the LayerNorm-folded weights of qkv and project_in and the operand fragments of */
+/* project_out (model/Restromer.py:26-52 folded into :130,:100; :103) into a       */
+/* caller-owned device buffer of rst_block_prepared_bytes (depends on C, hidden and */
+/* the flags only); it stays valid until a parameter changes.                      */
+/* rst_block_fwd_prepared == rst_block_fwd with saved == NULL, minus those launches. */
+size_t rst_block_prepared_bytes(const rst_block_desc* desc);
+int rst_block_prepare(const rst_block_desc* desc, const rst_block_params* params, void* prepared, void* stream);
+int rst_block_fwd_prepared(const rst_block_desc* desc, const rst_block_params* params, const void* prepared,
+                           const float* x, float* y, void* workspace, size_t workspace_bytes, void* stream);
 size_t rst_block_bwd_workspace_bytes(const rst_block_desc* desc);
 int rst_block_bwd(const rst_block_desc* desc, const rst_block_params* params,
                   const float* x, const float* dy, const void* saved,

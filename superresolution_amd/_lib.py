@@ -78,6 +78,9 @@ SIGNATURES = {
     "rst_block_workspace_bytes": (c_size_t, [_DESC]),
     "rst_block_saved_bytes": (c_size_t, [_DESC]),
     "rst_block_fwd": (c_int32, [_DESC, _PAR, _P, _P, _P, _P, c_size_t, _P]),
+    "rst_block_prepared_bytes": (c_size_t, [_DESC]),
+    "rst_block_prepare": (c_int32, [_DESC, _PAR, _P, _P]),
+    "rst_block_fwd_prepared": (c_int32, [_DESC, _PAR, _P, _P, _P, _P, c_size_t, _P]),
     "rst_block_bwd_workspace_bytes": (c_size_t, [_DESC]),
     "rst_block_shard_workspace_bytes": (c_size_t, [_DESC]),
     "rst_block_shard_stats_floats": (c_size_t, [_DESC]),

@@ -64,6 +64,7 @@ struct LnIn {
     const float* gamma;
     const float* beta;      // null: bias-free variant
     float* scratch;         // B*C*N floats
+    const float* ready;     // folded weights prepared ahead (rst_block_prepare) in the form fold_kind() names, or null
 };
 // (also holds the split-f16 operand fragments of the folded weights: rows padded to 16, columns to 32)
 static size_t ln_fold_floats(int Cout, int Cin) { return (size_t)round_up(Cout, 16) * round_up(Cin, 32) + 2 * (size_t)round_up(Cout, 16); }
@@ -76,25 +77,38 @@ static int f16s_min_k() {
     return v;
 }
 static bool use_f16s(const GemmNN& g) { return gemm_f16s_enabled() && g.K >= f16s_min_k() && gemm_f16s_supported(g); }
+// which form a product with Cin input channels wants its folded weights in: 1 = split-f16 operand fragments, 0 = fp32 matrix
+static int fold_kind(int Cin) { return gemm_f16s_enabled() && Cin >= f16s_min_k() ? 1 : 0; }
+static int fold_prepare(int kind, const float* w, const float* gamma, const float* beta, const float* bias, int Cout, int Cin,
+                        float* fold, hipStream_t stream) {
+    if (kind == 1) {
+        float* s = fold + (size_t)round_up(Cout, 16) * round_up(Cin, 32);
+        return gemm_f16s_prep_launch(w, 0, 1, Cin, 0, gamma, beta, bias, Cout, Cin, fold, 0, s, s + round_up(Cout, 16), stream);
+    }
+    float* s = fold + (size_t)Cout * Cin;
+    return ln_fold_weights_launch(w, gamma, beta, bias, Cout, Cin, fold, s, s + Cout, stream);
+}
 
 // y = conv1x1(LN(x)) (+bias), through the folded path when possible
 static int ln_conv1x1(const LnIn& ln, const float* w, const float* bias, int Cout, int Cin, const float* x, float* y,
                       int B, int64_t N, float* fold, hipStream_t stream) {
     GemmNN g = conv1x1_args(w, Cout, Cin, false, x, y, B, N);
     if (use_f16s(g)) {
-        float* s = fold + (size_t)round_up(Cout, 16) * round_up(Cin, 32);
-        float* c = s + round_up(Cout, 16);
-        RST_TRY(gemm_f16s_prep_launch(w, 0, 1, Cin, 0, ln.gamma, ln.beta, bias, Cout, Cin, fold, 0, s, c, stream));
-        g.afrag = fold; g.ln_mode = ln.beta ? 1 : 2; g.ln_s = s; g.ln_c = c;
+        const bool have = ln.ready != nullptr && fold_kind(Cin) == 1;
+        if (!have) RST_TRY(fold_prepare(1, w, ln.gamma, ln.beta, bias, Cout, Cin, fold, stream));
+        const float* f = have ? ln.ready : fold;
+        const float* s = f + (size_t)round_up(Cout, 16) * round_up(Cin, 32);
+        g.afrag = f; g.ln_mode = ln.beta ? 1 : 2; g.ln_s = s; g.ln_c = s + round_up(Cout, 16);
         return gemm_nn_launch(g, stream);
     }
     GemmNN probe = g;
     probe.A = fold;
     if (gemm_nn_ln_supported(probe)) {
-        float* s = fold + (size_t)Cout * Cin;
-        float* c = s + Cout;
-        RST_TRY(ln_fold_weights_launch(w, ln.gamma, ln.beta, bias, Cout, Cin, fold, s, c, stream));
-        g.A = fold; g.ln_mode = ln.beta ? 1 : 2; g.ln_s = s; g.ln_c = c;
+        const bool have = ln.ready != nullptr && fold_kind(Cin) == 0;
+        if (!have) RST_TRY(fold_prepare(0, w, ln.gamma, ln.beta, bias, Cout, Cin, fold, stream));
+        const float* f = have ? ln.ready : fold;
+        const float* s = f + (size_t)Cout * Cin;
+        g.A = f; g.ln_mode = ln.beta ? 1 : 2; g.ln_s = s; g.ln_c = s + Cout;
         return gemm_nn_launch(g, stream);
     }
     RST_TRY(layernorm_fwd_launch(x, ln.gamma, ln.beta, ln.scratch, B, Cin, N, stream));
@@ -122,10 +136,11 @@ static int ln_pw_dw(const LnIn* ln, const float* w, const float* bias, const flo
     static const bool off = getenv("RST_FUSE_PWDW") != nullptr && getenv("RST_FUSE_PWDW")[0] == '0';
     if (off || !pwdw_profitable(a)) return RST_OK;
     if (ln) {
-        float* s = fold + (size_t)Cout * Cin;
-        float* c = s + Cout;
-        RST_TRY(ln_fold_weights_launch(w, ln->gamma, ln->beta, bias, Cout, Cin, fold, s, c, stream));
-        a.A = fold; a.ln_mode = ln->beta ? 1 : 2; a.ln_s = s; a.ln_c = c;
+        const bool have = ln->ready != nullptr && fold_kind(Cin) == 0;
+        if (!have) RST_TRY(fold_prepare(0, w, ln->gamma, ln->beta, bias, Cout, Cin, fold, stream));
+        const float* f = have ? ln->ready : fold;
+        const float* s = f + (size_t)Cout * Cin;
+        a.A = f; a.ln_mode = ln->beta ? 1 : 2; a.ln_s = s; a.ln_c = s + Cout;
     }
     RST_TRY(pwdw_launch(a, stream));
     *done = true;
@@ -456,7 +471,8 @@ static size_t ffn_saved_bytes(const rst_block_desc* d) {
 
 // `ln` (optional, only without `saved`): as in attention_fwd, for the LayerNorm in front of project_in
 static int ffn_fwd(const rst_block_desc* d, const rst_block_params* p, const float* x, const float* residual, float* y,
-                   void* saved, void* ws, size_t ws_bytes, hipStream_t stream, const LnIn* ln = nullptr) {
+                   void* saved, void* ws, size_t ws_bytes, hipStream_t stream, const LnIn* ln = nullptr,
+                   const void* pout_ready = nullptr) {
     RST_REQUIRE(x && y && p, "ffn_fwd: null operand");
     RST_REQUIRE(p->pin_weight && p->ffn_dw_weight && p->pout_weight, "ffn_fwd: null parameter");
     RST_REQUIRE(!d->conv_bias || (p->pin_bias && p->ffn_dw_bias && p->pout_bias), "ffn_fwd: conv_bias set but a bias is null");
@@ -497,8 +513,12 @@ static int ffn_fwd(const rst_block_desc* d, const rst_block_params* p, const flo
     g2.bias = d->conv_bias ? p->pout_bias : nullptr;
     g2.R = residual; g2.r_s1 = (int64_t)C * N; g2.r_s2 = 0; g2.ldr = N;
     if (pfrag != nullptr && use_f16s(g2)) {
-        RST_TRY(gemm_f16s_prep_launch(p->pout_weight, 0, 1, Hd, 0, nullptr, nullptr, nullptr, C, Hd, pfrag, 0, nullptr, nullptr, stream));
-        g2.afrag = pfrag;
+        if (pout_ready != nullptr && fold_kind(Hd) == 1) {
+            g2.afrag = pout_ready;
+        } else {
+            RST_TRY(gemm_f16s_prep_launch(p->pout_weight, 0, 1, Hd, 0, nullptr, nullptr, nullptr, C, Hd, pfrag, 0, nullptr, nullptr, stream));
+            g2.afrag = pfrag;
+        }
     }
     return gemm_nn_launch(g2, stream);
 }
@@ -580,8 +600,37 @@ static size_t block_ws_bytes(const rst_block_desc* d) {
     return cv.total();
 }
 
+// what does not depend on the input: both LayerNorm-folded weight sets and the fragments of project_out
+struct BlockPrepared { float *fold_qkv, *fold_pin; void* pout_frag; };
+static void block_carve_prepared(const rst_block_desc* d, Carver& cv, BlockPrepared& b) {
+    b.fold_qkv = cv.floats(ln_fold_floats(3 * d->C, d->C));
+    b.fold_pin = cv.floats(ln_fold_floats(2 * d->hidden, d->C));
+    b.pout_frag = cv.bytes(gemm_f16s_frag_bytes(d->C, d->hidden));
+}
+static size_t block_prepared_bytes(const rst_block_desc* d) {
+    Carver cv(nullptr); BlockPrepared b{};
+    block_carve_prepared(d, cv, b);
+    return cv.total();
+}
+static int block_prepare(const rst_block_desc* d, const rst_block_params* p, void* prepared, hipStream_t stream) {
+    RST_REQUIRE(p && prepared, "block_prepare: null operand");
+    RST_REQUIRE(p->norm1_weight && p->norm2_weight && p->qkv_weight && p->pin_weight && p->pout_weight, "block_prepare: null parameter");
+    RST_REQUIRE(!d->ln_with_bias || (p->norm1_bias && p->norm2_bias), "block_prepare: ln_with_bias set but a bias is null");
+    RST_REQUIRE(!d->conv_bias || (p->qkv_bias && p->pin_bias), "block_prepare: conv_bias set but a bias is null");
+    Carver cp(prepared); BlockPrepared b{};
+    block_carve_prepared(d, cp, b);
+    const int C = d->C, Hd = d->hidden;
+    RST_TRY(fold_prepare(fold_kind(C), p->qkv_weight, p->norm1_weight, d->ln_with_bias ? p->norm1_bias : nullptr,
+                         d->conv_bias ? p->qkv_bias : nullptr, 3 * C, C, b.fold_qkv, stream));
+    RST_TRY(fold_prepare(fold_kind(C), p->pin_weight, p->norm2_weight, d->ln_with_bias ? p->norm2_bias : nullptr,
+                         d->conv_bias ? p->pin_bias : nullptr, 2 * Hd, C, b.fold_pin, stream));
+    if (fold_kind(Hd) == 1)
+        RST_TRY(gemm_f16s_prep_launch(p->pout_weight, 0, 1, Hd, 0, nullptr, nullptr, nullptr, C, Hd, b.pout_frag, 0, nullptr, nullptr, stream));
+    return RST_OK;
+}
+
 static int block_fwd(const rst_block_desc* d, const rst_block_params* p, const float* x, float* y, void* saved,
-                     void* ws, size_t ws_bytes, hipStream_t stream) {
+                     void* ws, size_t ws_bytes, hipStream_t stream, const void* prepared = nullptr) {
     RST_REQUIRE(x && y && p, "block_fwd: null operand");
     RST_REQUIRE(p->norm1_weight && p->norm2_weight, "block_fwd: null LayerNorm weight");
     RST_REQUIRE(!d->ln_with_bias || (p->norm1_bias && p->norm2_bias), "block_fwd: ln_with_bias set but a bias is null");
@@ -602,10 +651,12 @@ static int block_fwd(const rst_block_desc* d, const rst_block_params* p, const f
     }
     if (!saved) {
         // inference: the normalised tensors are consumed by one product each and never stored
-        const LnIn ln1{p->norm1_weight, d->ln_with_bias ? p->norm1_bias : nullptr, xn};
-        const LnIn ln2{p->norm2_weight, d->ln_with_bias ? p->norm2_bias : nullptr, xn};
+        BlockPrepared pre{};
+        if (prepared != nullptr) { Carver cp(const_cast<void*>(prepared)); block_carve_prepared(d, cp, pre); }
+        const LnIn ln1{p->norm1_weight, d->ln_with_bias ? p->norm1_bias : nullptr, xn, pre.fold_qkv};
+        const LnIn ln2{p->norm2_weight, d->ln_with_bias ? p->norm2_bias : nullptr, xn, pre.fold_pin};
         RST_TRY(attention_fwd(d, p, x, x, x1, nullptr, sub, sub_bytes, stream, &ln1));
-        return ffn_fwd(d, p, x1, x1, y, nullptr, sub, sub_bytes, stream, &ln2);
+        return ffn_fwd(d, p, x1, x1, y, nullptr, sub, sub_bytes, stream, &ln2, pre.pout_frag);
     }
     RST_TRY(layernorm_fwd_launch(x, p->norm1_weight, d->ln_with_bias ? p->norm1_bias : nullptr, xn1, B, C, N, stream));
     RST_TRY(attention_fwd(d, p, xn1, x, x1, s.attn, sub, sub_bytes, stream));
@@ -661,7 +712,7 @@ static int block_shard_stats(const rst_block_desc* d, const rst_block_params* p,
     shard_carve(d, row1 - row0, cw, sb);
     AttnBufs b{}; Carver ca(sb.sub);
     attn_carve_ws(d, false, ca, b);
-    const LnIn ln1{p->norm1_weight, d->ln_with_bias ? p->norm1_bias : nullptr, sb.xn};
+    const LnIn ln1{p->norm1_weight, d->ln_with_bias ? p->norm1_bias : nullptr, sb.xn, nullptr};
     RST_TRY(attention_qkv(d, p, x, b, false, &ln1, stream));
     RST_TRY(attention_gram(d, b, sb.plan, row0, row1, sb.gram_part, sb.sqq_part, sb.sqk_part, stream));
     float* sq = stats + (size_t)B * heads * c * c;
@@ -680,7 +731,7 @@ static int block_shard_apply(const rst_block_desc* d, const rst_block_params* p,
     AttnBufs b{}; Carver ca(sb.sub);
     attn_carve_ws(d, false, ca, b);                       // same carving as phase 1: b.qkv still holds the slab's qkv
     RST_TRY(attention_tail(d, p, b, x, y, 0, d->H, stats, stream));
-    const LnIn ln2{p->norm2_weight, d->ln_with_bias ? p->norm2_bias : nullptr, sb.xn};
+    const LnIn ln2{p->norm2_weight, d->ln_with_bias ? p->norm2_bias : nullptr, sb.xn, nullptr};
     return ffn_fwd(d, p, y, y, y, nullptr, sb.sub, sb.sub_bytes, stream, &ln2);
 }
 
@@ -913,6 +964,17 @@ int rst_block_fwd(const rst_block_desc* d, const rst_block_params* p, const floa
                   void* workspace, size_t workspace_bytes, void* stream) {
     RST_TRY(check_desc(d));
     return block_fwd(d, p, x, y, saved, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+size_t rst_block_prepared_bytes(const rst_block_desc* d) { return check_desc(d) == RST_OK ? block_prepared_bytes(d) : 0; }
+int rst_block_prepare(const rst_block_desc* d, const rst_block_params* p, void* prepared, void* stream) {
+    RST_TRY(check_desc(d));
+    return block_prepare(d, p, prepared, static_cast<hipStream_t>(stream));
+}
+int rst_block_fwd_prepared(const rst_block_desc* d, const rst_block_params* p, const void* prepared, const float* x, float* y,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+    RST_TRY(check_desc(d));
+    RST_REQUIRE(prepared != nullptr, "block_fwd_prepared: null prepared buffer");
+    return block_fwd(d, p, x, y, nullptr, workspace, workspace_bytes, static_cast<hipStream_t>(stream), prepared);
 }
 size_t rst_block_shard_workspace_bytes(const rst_block_desc* d) { return check_desc(d) == RST_OK ? block_shard_ws_bytes(d) : 0; }
 size_t rst_block_shard_stats_floats(const rst_block_desc* d) { return check_desc(d) == RST_OK ? block_shard_stats_floats(d) : 0; }

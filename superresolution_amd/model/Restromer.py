@@ -142,7 +142,9 @@ class TransformerBlock(nn.Module):
         }
 
     def forward(self, x):
-        return ops.transformer_block(x, self.attn.num_heads, self.ffn.hidden_features, self._params())
+        if getattr(self, "_f32_cache", None) is None:
+            self._f32_cache = ops.PreparedBlock()
+        return ops.transformer_block(x, self.attn.num_heads, self.ffn.hidden_features, self._params(), self._f32_cache)
 
 
 class OverlapPatchEmbed(nn.Module):
@@ -243,9 +245,10 @@ class Restormer(nn.Module):
         """Drop the prepared bf16 weights of every block (needed only after parameter writes that bypass torch's
         version counter, i.e. through ``param.data``)."""
         for m in self.modules():
-            cache = getattr(m, "_pk_cache", None)
-            if cache is not None:
-                cache.invalidate()
+            for name in ("_pk_cache", "_f32_cache"):
+                cache = getattr(m, name, None)
+                if cache is not None:
+                    cache.invalidate()
 
     def _apply(self, fn, *args, **kwargs):
         # .to() / .float() / .cuda() may replace parameter storage behind the same version number

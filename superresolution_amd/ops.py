@@ -526,13 +526,52 @@ def feed_forward(x, hidden, pin_weight, pin_bias, dw_weight, dw_bias, pout_weigh
                         pin_weight, pin_bias, dw_weight, dw_bias, pout_weight, pout_bias)
 
 
-def transformer_block(x, heads, hidden, params: Dict[str, Optional[torch.Tensor]]):
+class PreparedBlock:
+    """The input-independent part of one block's fp32 inference (rst_block_prepare: LayerNorm-folded weights, operand
+    fragments), kept between calls and rebuilt when a parameter tensor is replaced or modified in place (torch bumps
+    ``_version`` on every in-place write).  A write through ``param.data`` does not move ``_version``: call
+    :meth:`invalidate` after such a write."""
+    __slots__ = ("key", "blob")
+
+    def __init__(self):
+        self.key, self.blob = None, None
+
+    def invalidate(self):
+        self.key, self.blob = None, None
+
+    def get(self, lib, desc, par, tensors, device):
+        key = tuple((n, t.data_ptr(), t._version) for n, t in tensors.items() if t is not None) + (str(device),)
+        if key != self.key:
+            blob = torch.empty(lib.rst_block_prepared_bytes(ctypes.byref(desc)), dtype=torch.uint8, device=device)
+            check(lib.rst_block_prepare(ctypes.byref(desc), ctypes.byref(par), _ptr(blob), _stream()), "rst_block_prepare")
+            self.key, self.blob = key, blob
+        return self.blob
+
+
+def transformer_block(x, heads, hidden, params: Dict[str, Optional[torch.Tensor]], cache: Optional[PreparedBlock] = None):
     """TransformerBlock (reference: model/Restromer.py:163-167).  `params` maps
-    the names in PARAM_FIELDS to tensors (None for absent biases)."""
+    the names in PARAM_FIELDS to tensors (None for absent biases).  With a `cache` an inference call (no autograd
+    graph wanted) reuses the block's prepared weights (rst_block_fwd_prepared)."""
     ln_with_bias = params.get("norm1_bias") is not None
     conv_bias = params.get("qkv_bias") is not None
     ps = [params.get(n) for n in PARAM_FIELDS]
-    return _BlockFn.apply(x, heads, hidden, ln_with_bias, conv_bias, _keep(x, ps), *ps)
+    keep = _keep(x, ps)
+    if cache is not None and not keep:
+        lib = _lib.load()
+        x = _require(x, "block x")
+        B, C, H, W = x.shape
+        if C % heads:
+            raise RuntimeError(f"block: channels {C} not divisible by heads {heads}")
+        tensors = {n: (None if params.get(n) is None else _require(params[n], f"block {n}")) for n in PARAM_FIELDS}
+        desc = make_desc(B, C, H, W, heads, hidden, ln_with_bias, conv_bias)
+        par = _fill(BlockParams(), tensors)
+        prepared = cache.get(lib, desc, par, {n: params.get(n) for n in PARAM_FIELDS}, x.device)
+        ws = workspace(lib.rst_block_workspace_bytes(ctypes.byref(desc)), x.device)
+        y = torch.empty_like(x)
+        check(lib.rst_block_fwd_prepared(ctypes.byref(desc), ctypes.byref(par), _ptr(prepared), _ptr(x), _ptr(y), _ptr(ws),
+                                         ws.numel(), _stream()), "rst_block_fwd_prepared")
+        return y
+    return _BlockFn.apply(x, heads, hidden, ln_with_bias, conv_bias, keep, *ps)
 
 
 def block_forward_inplace(x, heads, hidden, params: Dict[str, Optional[torch.Tensor]]):
