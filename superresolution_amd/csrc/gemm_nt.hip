@@ -486,6 +486,7 @@ int gemm_nt_launch(GemmNT g, const NtPlan& p, hipStream_t stream) {
     RST_REQUIRE(g.M1 > 0 && g.M2 > 0 && g.N > 0 && g.nb1 > 0 && g.nb2 > 0, "gemm_nt: empty problem");
     RST_REQUIRE(g.A && g.Bm && g.partial, "gemm_nt: null operand");
     g.splits = p.splits; g.chunk = p.chunk;
+    if (gram_f16s_supported(g)) return gram_f16s_launch(g, stream);        // (RST_F32_MFMA=1 keeps the exact-fp32 kernel)
     const int WR = p.d1.W, WC = p.d2.W;
     const int64_t grid = (int64_t)g.nb1 * g.nb2 * p.splits * p.d1.blocks * p.d2.blocks;
     RST_REQUIRE(grid < (1ll << 31), "gemm_nt: grid too large");

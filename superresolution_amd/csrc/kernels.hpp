@@ -101,6 +101,9 @@ struct NtPlan { NtDim d1, d2; int splits; int64_t chunk; };
 NtPlan gemm_nt_plan(int M1, int M2, int64_t N, int nbatch, int max_splits_cap = 0);
 size_t gemm_nt_partial_floats(const NtPlan& p, int M1, int M2, int nbatch);
 int gemm_nt_launch(GemmNT g, const NtPlan& p, hipStream_t stream);
+// gram_f16s.hip: the Gram use of GemmNT (M1 == M2, both squared-norm outputs) on split-f16 operands; same slabs
+bool gram_f16s_supported(const GemmNT& g);
+int gram_f16s_launch(const GemmNT& g, hipStream_t stream);
 int reduce_slabs_launch(const float* partial, float* out, int64_t elems, int groups, int slabs_per_group,
                         int accumulate, hipStream_t stream);
 
