@@ -176,15 +176,23 @@ pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[i] = Xs[4 * i * ROWF];
                     ws_h8 hi, lo;
+                    typedef _Float16 ws_h2 __attribute__((ext_vector_type(2)));
+                    ws_f32x2 p1 = {0.f, 0.f}, p2 = {0.f, 0.f};
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const float x = cvalid ? v[i] : 0.f;
-                        const _Float16 h = (_Float16)x;
-                        hi[i] = h;
-                        lo[i] = (_Float16)((x - (float)h) * 2048.f);
-                        cs1 += x;
-                        cs2 = fmaf(x, x, cs2);
+                    for (int i = 0; i < 8; i += 2) {
+                        // two channels at a time: packed conversions, the residual (x - hi) * 2048 as fma(hi, -2048, 2048 x)
+                        const ws_f32x2 x = {cvalid ? v[i] : 0.f, cvalid ? v[i + 1] : 0.f};
+                        const ws_h2 h = __builtin_convertvector(x, ws_h2);
+                        const ws_f32x2 sc = x * 2048.f;
+                        const ws_f32x2 r2 = {fmaf((float)h[0], -2048.f, sc[0]), fmaf((float)h[1], -2048.f, sc[1])};
+                        const ws_h2 l = __builtin_convertvector(r2, ws_h2);
+                        hi[i] = h[0]; hi[i + 1] = h[1];
+                        lo[i] = l[0]; lo[i + 1] = l[1];
+                        p1 += x;
+                        p2 += x * x;
                     }
+                    cs1 += p1[0] + p1[1];
+                    cs2 += p2[0] + p2[1];
                     img[((buf * 5 + slab) * 2 + 0) * 64 + lane] = hi;
                     img[((buf * 5 + slab) * 2 + 1) * 64 + lane] = lo;
                 }
