@@ -39,6 +39,12 @@ def group(name):
         return "pwdw_gate_f16" if args[3] == "true" else "pwdw_f16"
     if k == "conv3x3_f16s_kernel":
         return "conv3x3_f16s"
+    if k == "gram_f16s_kernel":
+        return "gram_f16s"
+    if k == "conv3x3_pk_kernel":
+        return "pk_conv3x3"
+    if k == "wgrad_pk_kernel":
+        return "pk_wgrad"
     if k == "gemm_pk_kernel":
         return "pk_gemm_ln" if args[2] == "true" else "pk_gemm"
     if k == "dw_pk_kernel":
