@@ -366,9 +366,13 @@ pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
 
     // ================================ vector wave ================================
     const int dwave = slab;                              // 0 .. ND-1
-    // the vector waves are the younger waves of their SIMD and would only get the issue slots the matrix waves
-    // leave; they have the shorter stream and everyone waits for them at the chunk barrier: let them go first
-    __builtin_amdgcn_s_setprio(3);
+    // exact-fp32 form: the vector waves are the younger waves of their SIMD and would only get the issue slots the
+    // matrix waves leave; they have the shorter stream and everyone waits for them at the chunk barrier: let them go
+    // first.  In the split-f16 form the matrix waves carry the DMA stream, the conversion and the statistics as well,
+    // and a raised vector priority starves their DMA issue (barrier time stamps of one block: an issue of two DMA
+    // instructions took up to 5 000 cycles in the phase in which the vector waves run their taps): no priority there
+    // (7.64 -> 7.23 ms and 5.81 -> 5.51 ms per step for the plain and the gated kernel).
+    if constexpr (!F16S) __builtin_amdgcn_s_setprio(3);
     for (int i = tid - NM * 64; i < 2 * ROWF; i += ND * 64) { statm[i] = 0.f; statr[i] = 1.f; }     // (0, 1) = no LayerNorm
     const int tv0 = part * TV;                           // first tile of this wave
     float wv[NH][9], lns[NH], lnc[NH], bq[NH];
