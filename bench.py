@@ -94,7 +94,19 @@ def dist_setup(n_gpus: int):
         # launched by torch.distributed.run (also with one rank: the RCCL paths then run as they do with eight)
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        # RCCL prints a version banner on stdout when its first communicator comes up: create it here with stdout
+        # pointed at stderr, so that the JSON line stays the only thing this program writes to stdout
+        sys.stdout.flush()
+        keep = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+            dist.all_reduce(torch.zeros(1, device=torch.device("cuda", local)))
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(keep, 1)
+            os.close(keep)
     else:
         torch.cuda.set_device(0)
     if world != n_gpus:
