@@ -93,7 +93,7 @@ static int fold_prepare(int kind, const float* w, const float* gamma, const floa
 static int ln_conv1x1(const LnIn& ln, const float* w, const float* bias, int Cout, int Cin, const float* x, float* y,
                       int B, int64_t N, float* fold, hipStream_t stream) {
     GemmNN g = conv1x1_args(w, Cout, Cin, false, x, y, B, N);
-    if (use_f16s(g)) {
+    if (Cin % 2 == 0 && use_f16s(g)) {
         const bool have = ln.ready != nullptr && fold_kind(Cin) == 1;
         if (!have) RST_TRY(fold_prepare(1, w, ln.gamma, ln.beta, bias, Cout, Cin, fold, stream));
         const float* f = have ? ln.ready : fold;

@@ -178,13 +178,11 @@ static int pk_block_fwd(const rst_block_desc* d, const rst_block_params* p, cons
     const int64_t cn = (int64_t)C * N;
 
     // ---- MDTA (model/Restromer.py:128-150) ----
-    // The fused 1x1 + depthwise kernel is routed where it was measured ahead of the pair of kernels: the qkv
-    // product at 96 channels (398 vs 420 us at 16 x 96 x 256 x 256; the gated form 399 vs 387 us, 48 channels
-    // 302 vs 212 us).  RST_BF16_FUSE=0: never, =2: wherever the kernel supports the shape (tests).
+    // The fused 1x1 + depthwise kernel (pwdw_ring_kernel: the intermediate stays in LDS) takes both pairs wherever it
+    // supports the shape (at most 96 input channels).  RST_BF16_FUSE=0: never (tests, A/B runs)
     static const int fuse_mode = getenv("RST_BF16_FUSE") != nullptr ? atoi(getenv("RST_BF16_FUSE")) : 1;
-    const bool fuse_ok = fuse_mode > 0 && pwdw_pk_supported(C / 8, d->W, d->H);
-    const bool fuse = fuse_ok && (fuse_mode == 2 || gemm_pk_ks(C / 8) == 3);
-    const bool fuse_gate = fuse_ok && fuse_mode == 2;
+    const bool fuse = fuse_mode > 0 && pwdw_pk_supported(C / 8, d->W, d->H);
+    const bool fuse_gate = fuse;
     if (fuse) {
         PwDwPk f{};
         f.A = b.wqkv.frag; f.X = x; f.x_bs = cn; f.Y = qkv; f.y_bs = 3 * cn;

@@ -730,68 +730,138 @@ pwdw_pk_kernel(const PwDwPk g) {
 }
 
 // ---- fused 1x1 (folded LayerNorm) -> depthwise 3x3 (-> gate), both on the matrix pipe ----------------------
-// A block owns a strip of 32 columns (30 stored + the halo column on either side), all channels, and walks down a
-// range of rows.  Phase G: the 1x1 product of a row of the strip, LayerNorm epilogue, zero outside the image, packed
-// to bf16 chunks and written into a ring of 4 rows in LDS -- the chunks are written exactly as the depthwise
-// convolution's B operand wants them.  Phase D (every second row): the depthwise convolution of two output rows
-// as in dwm_pk_kernel, its operand chunks read from the ring with ds_read_b128, the tap matrices of the wave's
-// channel blocks resident in registers.  The intermediate never leaves the CU, nothing is unpacked, and the vector
-// unit only runs the two epilogues.  A wave takes every NWV-th tile pair in G and every NWV-th channel block in D.
-// grid = (strips * row ranges, 1, samples)
-template <int KS, int CBW, bool GATE, int NWV>
-__global__ void __launch_bounds__(64 * NWV)
-pwdw_ring_kernel(const PwDwPk g) {
+// A block owns a strip of 32 columns (30 stored + the halo column on either side) and a range of rows; each of its
+// waves owns ONE pair of row tiles of the 1x1 product = 4 channel blocks of the intermediate, for the whole strip,
+// and walks down the rows on its own:
+//   G (row r): the 1x1 product of the row for the wave's pair (weights resident in registers, the pixel operand
+//     straight from memory, the next rows' already in flight), LayerNorm epilogue, zero outside the image, packed
+//     to bf16 chunks into the wave's PRIVATE ring of 4 rows in LDS -- written exactly as the depthwise
+//     convolution's B operand wants them;
+//   D (rows y, y+1): the depthwise convolution as in dwm_pk_kernel, its operand chunks read from the ring with
+//     ds_read_b128; the tap matrices (one non-zero per lane and k-step) are rebuilt from one register each.
+// A wave is the only producer and the only consumer of its ring, LDS operations of a wave complete in order, so
+// the row loop has NO barrier: the waves of a CU drift apart and fill each other's latencies.  The intermediate
+// never leaves the CU, nothing is unpacked, and the vector unit only runs the two epilogues.  What the waves share
+// are the LayerNorm statistics of the strip's rows: taken once per block in a prologue (on the matrix pipe as well),
+// kept in LDS, one barrier.
+// grid = (strips * row ranges, groups of `nwb` pairs, samples), nwb <= 8 waves per block
+template <int KS, bool GATE>
+__global__ void __launch_bounds__(512)
+pwdw_ring_kernel(const PwDwPk g, int nwb) {
     constexpr int TW = 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int Mb = g.Mb, npairs = (Mb + 3) / 4;
-    bf16x8* As = reinterpret_cast<bf16x8*>(smem);                                    // [npairs*2][KS][64]
-    float* sc = reinterpret_cast<float*>(smem + (size_t)npairs * 2 * KS * 1024);    // [2][npairs*32]
-    char* ring = smem + (size_t)npairs * 2 * KS * 1024 + (size_t)npairs * 32 * 2 * sizeof(float);   // [4][Mb][TW] chunks
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float2* stat = reinterpret_cast<float2*>(smem);                                  // [rows + 2][TW]: mean (or 0), 1/sigma
+    float* sc = reinterpret_cast<float*>(smem + (size_t)(g.rows + 2) * TW * 8);      // [2][nwb * 32]
+    float* dbias = sc + 2 * nwb * 32;                                                // [nwb][4 blocks][16]: depthwise bias of accumulator row 4 gq + r
+    char* ring_all = reinterpret_cast<char*>(dbias + nwb * 64);                      // [nwb][4 rows][4 blocks][TW] chunks
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // (uniform: the store descriptors are built from it)
     const int n_ = lane & 15, gq = lane >> 4;
     const int b = blockIdx.z;
-    {
-        const u32x4* src = reinterpret_cast<const u32x4*>(g.A);
-        u32x4* dst = reinterpret_cast<u32x4*>(smem);
-        for (int i = tid; i < npairs * 2 * KS * 64; i += 64 * NWV) dst[i] = src[i];
-        for (int i = tid; i < npairs * 32; i += 64 * NWV) { sc[i] = g.ln_s[i]; sc[npairs * 32 + i] = g.ln_c[i]; }
-    }
-    const int H = g.H, W = g.W;
+    const int Mb = g.Mb, npairs = (Mb + 3) / 4;
+    const int pair = blockIdx.y * nwb + wave;
+    const int H = g.H, W = g.W, Kb = g.Kb;
     const int64_t N = (int64_t)H * W;
     const int nstrips = (W + 29) / 30;
     const int strip = blockIdx.x % nstrips, range = blockIdx.x / nstrips;
     const int x0 = strip * 30 - 1;                                   // image column of strip column 0
     const int y_begin = range * g.rows;
     const int y_end = y_begin + g.rows < H ? y_begin + g.rows : H;
+    const int r0 = y_begin - 1;
     const bf16x8* Xp = reinterpret_cast<const bf16x8*>(g.X + (int64_t)b * g.x_bs);
     char* Yb = reinterpret_cast<char*>(g.Y + (int64_t)b * g.y_bs);
-    const float invK = 1.0f / (float)g.K;
-    const int Kb = g.Kb;
-    auto pos_of = [](int q) { return GATE ? ((q & 1) ? 4 + (q >> 1) : (q >> 1)) : q; };
-
-    // tap matrices of this wave's channel blocks (cb = wave + NWV j), as in dwm_pk_kernel, and the biases of the
-    // lane's 4 accumulator rows
-    bf16x8 dwa[CBW][3];
-    float dbias[CBW][4];
+    char* myring = ring_all + (size_t)wave * (4 * 4 * TW * 16);
+    {
+        const u32x4 z = {0u, 0u, 0u, 0u};                           // rows a short range never writes must stay finite
 #pragma unroll
-    for (int j = 0; j < CBW; ++j) {
-        const int cb = wave + NWV * j;
+        for (int i = 0; i < 8; ++i) reinterpret_cast<u32x4*>(myring)[i * 64 + lane] = z;
+        for (int i = tid; i < nwb * 32; i += 64 * nwb) {
+            const int p = blockIdx.y * nwb * 32 + i;
+            sc[i] = p < npairs * 32 ? g.ln_s[p] : 0.f;
+            sc[nwb * 32 + i] = p < npairs * 32 ? g.ln_c[p] : 0.f;
+        }
+    }
+    // clamped column of strip column 16 nt + n_, and the chunk offsets of this lane's KS channel blocks
+    int xc[2]; bool x_in[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int x = x0 + 16 * nt + n_;
+        xc[nt] = x < 0 ? 0 : (x < W ? x : W - 1);
+        x_in[nt] = x >= 0 && x < W;
+    }
+    // (channel blocks past Kb read block 0: the weights of those positions are zero, so the product ignores them and
+    // nothing has to wait for the load to mask it; the statistics mask them)
+    auto xchunk = [&](int ks, int ry, int nt) -> bf16x8 {
+        const int yc = ry < 0 ? 0 : (ry < H ? ry : H - 1);
+        const int cb = 4 * ks + gq;
+        return Xp[(int64_t)(cb < Kb ? cb : 0) * N + (int64_t)yc * W + xc[nt]];
+    };
+    // ---- LayerNorm statistics of rows r0 .. y_end of the strip: task = (row, half of the strip), four in flight ----
+    {
+        const float invK = 1.0f / (float)g.K;
+        const u32x4 ones_w = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+        const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_w);
+        const int ntask = 2 * (y_end - r0 + 1);
+        for (int t0 = wave; t0 < ntask; t0 += 4 * nwb) {
+            bf16x8 xs[4][KS];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + u * nwb < ntask ? t0 + u * nwb : t0;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) xs[u][ks] = xchunk(ks, r0 + (t >> 1), t & 1);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                // on the matrix pipe, exactly (bf16 products, fp32 sums): ones^T X gives the channel sum of pixel n_
+                // in every accumulator row, X^T X the sum of squares on its diagonal (row n_ = lane group n_ / 4)
+                const int t = t0 + u * nwb;
+                f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                    const bf16x8 xv = 4 * ks + gq < Kb ? xs[u][ks] : z;
+                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xv, a1, 0, 0, 0);
+                    a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xv, xv, a2, 0, 0, 0);
+                }
+                const int rsel = n_ & 3;
+                const float s1 = a1[0];
+                const float s2 = rsel == 0 ? a2[0] : rsel == 1 ? a2[1] : rsel == 2 ? a2[2] : a2[3];
+                const float m = s1 * invK;
+                const float var = fmaxf(s2 * invK - m * m, 0.f);
+                if (gq == (n_ >> 2) && t < ntask) stat[(t >> 1) * TW + 16 * (t & 1) + n_] = float2{g.ln_mode == 1 ? m : 0.f, 1.0f / sqrtf(var + 1e-5f)};
+            }
+        }
+    }
+    __syncthreads();
+    if (pair >= npairs) return;                                      // (no barrier below)
+
+    auto pos_of = [](int q) { return GATE ? ((q & 1) ? 4 + (q >> 1) : (q >> 1)) : q; };
+    // weights of the pair: [half][k-step]
+    bf16x8 wa[2][KS];
+    {
+        const bf16x8* Ap = reinterpret_cast<const bf16x8*>(g.A) + (size_t)pair * 2 * KS * 64 + lane;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) wa[h][ks] = Ap[(h * KS + ks) * 64];
+    }
+    // taps of the wave's 4 channel blocks as in dwm_pk_kernel: this lane is matrix row m = n_, k-group gq; its one
+    // non-zero of k-step s3 sits in 32-bit word kq of the fragment
+    const int kq = pos_of(n_ & 7) >> 1;
+    uint32_t tapv[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int cb = 4 * pair + j;
         const float* wl = g.dww + (cb < Mb ? cb : 0) * 80;
-        const int m = n_, orow = m >> 3, p = pos_of(m & 7);
+        const int orow = n_ >> 3, p = pos_of(n_ & 7);
 #pragma unroll
         for (int s3 = 0; s3 < 3; ++s3) {
             const int t = 4 * s3 + gq, i = t / 3, d = t % 3, dy = i - orow;
-            float w = 0.f;
-            if (dy >= 0 && dy <= 2) w = wl[(dy * 3 + d) * 8 + p];
-            const uint32_t bits = to_bf16_bits(w);
-            u32x4 f = {0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if ((p >> 1) == k) f[k] = (p & 1) ? (bits << 16) : bits;
-            dwa[j][s3] = __builtin_bit_cast(bf16x8, f);
+            const float wr = wl[((dy < 0 ? 0 : (dy > 2 ? 2 : dy)) * 3 + d) * 8 + p];      // (no branch around the load)
+            const uint32_t bits = to_bf16_bits((dy >= 0 && dy <= 2) ? wr : 0.f);
+            tapv[j][s3] = (p & 1) ? (bits << 16) : bits;
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dbias[j][r] = wl[72 + pos_of((4 * gq + r) & 7)];
+        if (n_ < 4) dbias[(wave * 4 + j) * 16 + 4 * gq + n_] = wl[72 + pos_of((4 * gq + n_) & 7)];      // (read by this wave only)
     }
     // ring offsets of this lane's three operand chunks (k-step s3 -> slot 4 s3 + gq -> row offset, column)
     int drow[3], dcol[3][2];
@@ -802,129 +872,116 @@ pwdw_ring_kernel(const PwDwPk g) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int c = 16 * nt + n_ + t % 3 - 1;
-            dcol[s3][nt] = c < 0 ? 0 : (c < TW ? c : TW - 1);          // only the unstored halo columns clamp
+            dcol[s3][nt] = (c < 0 ? 0 : (c < TW ? c : TW - 1)) * 16;   // only the unstored halo columns clamp
         }
     }
-    __syncthreads();
+    const f32x4* sp = reinterpret_cast<const f32x4*>(sc + wave * 32 + gq * 8);
+    const f32x4* cp = reinterpret_cast<const f32x4*>(sc + nwb * 32 + wave * 32 + gq * 8);
+    const bool cb_ok = 4 * pair + gq < Mb;
+    const int plane_bytes = (int)__builtin_amdgcn_readfirstlane((int)(N * 16 - (GATE ? 8 : 0)));      // (N < 2^27: checked by the launcher)
 
-    // pixel operand of one row of the strip
     auto xload = [&](bf16x8 (&dst)[KS][2], int ry) {
-        const int yc = ry < 0 ? 0 : (ry < H ? ry : H - 1);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) dst[ks][nt] = xchunk(ks, ry, nt);
+    };
+    // G: row ry of the intermediate for the wave's 4 channel blocks -> ring
+    auto gemm_row = [&](const bf16x8 (&xf)[KS][2], int ry) {
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) acc[h][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0][ks], xf[ks][nt], acc[0][nt], 0, 0, 0);
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1][ks], xf[ks][nt], acc[1][nt], 0, 0, 0);
+            }
+        const f32x4 sa = sp[0], sb = sp[1], ca = cp[0], cc = cp[1];
+        const bool row_in = ry >= 0 && ry < H;
+        char* rrow = myring + (size_t)(((ry & 3) * 4 + gq) * TW) * 16;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const int x = x0 + 16 * nt + n_;
-            const int xc = x < 0 ? 0 : (x < W ? x : W - 1);
+            const float2 st = stat[(ry - r0) * TW + 16 * nt + n_];
+            float v[8];
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const int cb = 4 * ks + gq;
-                const bf16x8 v = Xp[(int64_t)(cb < Kb ? cb : 0) * N + (int64_t)yc * W + xc];
-                const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-                dst[ks][nt] = cb < Kb ? v : z;
+            for (int r = 0; r < 4; ++r) {
+                v[r] = fmaf(fmaf(-st.x, sa[r], acc[0][nt][r]), st.y, ca[r]);
+                v[4 + r] = fmaf(fmaf(-st.x, sb[r], acc[1][nt][r]), st.y, cc[r]);
             }
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            if (cb_ok) *reinterpret_cast<u32x4*>(rrow + (16 * nt + n_) * 16) = (row_in && x_in[nt]) ? pack8(v) : z;
         }
     };
-    // phase G for row ry
-    auto gemm_row = [&](const bf16x8 (&xf)[KS][2], int ry) {
-        float mean[2], rstd[2]; bool in[2];
+    // D: output rows y, y + 1 (the ring holds rows y-1 .. y+2); one channel block at a time, so that few operand
+    // chunks are live at once (the other waves of the SIMD cover the LDS latency)
+    auto dw_rows = [&](int y) {
+        const char* rbase[3];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            float s1 = 0.f, s2 = 0.f;
+        for (int s3 = 0; s3 < 3; ++s3) rbase[s3] = myring + (size_t)(((y + drow[s3]) & 3) * 4 * TW) * 16;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                float v[8];
-                unpack8(__builtin_bit_cast(u32x4, xf[ks][nt]), v);
+        for (int j = 0; j < 4; ++j) {
+            // (a channel block past Mb -- the last pair may be partial -- is computed on its all-zero ring rows and
+            // dropped by the stores: no branch, every path issues the same number of memory operations)
+            const int cb = 4 * pair + j < Mb ? 4 * pair + j : Mb - 1;
+            const bool cb_live = 4 * pair + j < Mb;
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { s1 += v[j]; s2 = fmaf(v[j], v[j], s2); }
-            }
-            s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-            const float m = s1 * invK;
-            const float var = fmaxf(s2 * invK - m * m, 0.f);
-            mean[nt] = g.ln_mode == 1 ? m : 0.f;
-            rstd[nt] = 1.0f / sqrtf(var + 1e-5f);
-            const int x = x0 + 16 * nt + n_;
-            in[nt] = ry >= 0 && ry < H && x >= 0 && x < W;
-        }
-        char* rrow = ring + (size_t)(ry & 3) * Mb * (TW * 16);
-        for (int p = wave; p < npairs; p += NWV) {
-            f32x4 acc[2][2];
+            for (int s3 = 0; s3 < 3; ++s3) {
+                u32x4 f;
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) acc[h][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const bf16x8* Ap = As + (size_t)p * 2 * KS * 64 + lane;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8 a0 = Ap[ks * 64], a1 = Ap[(KS + ks) * 64];
+                for (int k = 0; k < 4; ++k) f[k] = kq == k ? tapv[j][s3] : 0u;
+                const bf16x8 af = __builtin_bit_cast(bf16x8, f);
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, xf[ks][nt], acc[0][nt], 0, 0, 0);
-                    acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, xf[ks][nt], acc[1][nt], 0, 0, 0);
+                    // (read with the type the ring is written with: the compiler must see that these alias)
+                    const u32x4 bw = *reinterpret_cast<const u32x4*>(rbase[s3] + j * (TW * 16) + dcol[s3][nt]);
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, bw), acc[nt], 0, 0, 0);
                 }
             }
-            const int cb = p * 4 + gq;
-            if (cb >= Mb) continue;
-            const f32x4* sp = reinterpret_cast<const f32x4*>(sc + p * 32 + gq * 8);
-            const f32x4* cp = reinterpret_cast<const f32x4*>(sc + npairs * 32 + p * 32 + gq * 8);
-            const f32x4 sa = sp[0], sb = sp[1], ca = cp[0], cc = cp[1];
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(dbias + (wave * 4 + j) * 16 + 4 * gq);
+            const int yo = y + (gq >> 1);
+            // stores through a buffer descriptor over the channel block's plane: lanes outside the strip, the image or
+            // the row range get an offset past its end and are dropped -- no branch, so the compiler can count the
+            // stores and the next G waits for its operand loads only
+            const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
+                Yb + (GATE ? ((int64_t)(cb >> 1) * N * 16 + (cb & 1) * 8) : (int64_t)cb * N * 16), 0, plane_bytes, 0x00020000);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                float v[8];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[r] = fmaf(fmaf(-mean[nt], sa[r], acc[0][nt][r]), rstd[nt], ca[r]);
-                    v[4 + r] = fmaf(fmaf(-mean[nt], sb[r], acc[1][nt][r]), rstd[nt], cc[r]);
-                }
-                const u32x4 z = {0u, 0u, 0u, 0u};
-                *reinterpret_cast<u32x4*>(rrow + ((size_t)cb * TW + 16 * nt + n_) * 16) = in[nt] ? pack8(v) : z;
-            }
-        }
-    };
-    // phase D for output rows y, y + 1 (ring holds rows y-1 .. y+2)
-    auto dw_rows = [&](int y) {
-#pragma unroll
-        for (int j = 0; j < CBW; ++j) {
-            const int cb = wave + NWV * j;
-            if (cb >= Mb) break;
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int s3 = 0; s3 < 3; ++s3) {
-                    const char* src = ring + ((size_t)((y + drow[s3]) & 3) * Mb + cb) * (TW * 16) + dcol[s3][nt] * 16;
-                    const bf16x8 bfrag = *reinterpret_cast<const bf16x8*>(src);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dwa[j][s3], bfrag, acc, 0, 0, 0);
-                }
-                const int col = 16 * nt + n_, x = x0 + col, yo = y + (gq >> 1);
-                if (col >= 1 && col <= 30 && x < W && yo < y_end) {
-                    const int64_t px = (int64_t)yo * W + x;
-                    if (GATE) {
-                        const uint32_t o = pack_bf16(pk_gelu(acc[0] + dbias[j][0]) * (acc[1] + dbias[j][1]),
-                                                     pk_gelu(acc[2] + dbias[j][2]) * (acc[3] + dbias[j][3]));
-                        *reinterpret_cast<uint32_t*>(Yb + (((int64_t)(cb >> 1) * N + px) * 16 + (cb & 1) * 8 + (gq & 1) * 4)) = o;
-                    } else {
-                        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                        u32x2 o;
-                        o[0] = pack_bf16(acc[0] + dbias[j][0], acc[1] + dbias[j][1]);
-                        o[1] = pack_bf16(acc[2] + dbias[j][2], acc[3] + dbias[j][3]);
-                        *reinterpret_cast<u32x2*>(Yb + (((int64_t)cb * N + px) * 16 + (gq & 1) * 8)) = o;
-                    }
+                const int col = 16 * nt + n_, x = x0 + col;
+                const bool ok = cb_live && col >= 1 && col <= 30 && x < W && yo < y_end;
+                const unsigned vo = ok ? (unsigned)(yo * W + x) * 16u + (unsigned)(gq & 1) * (GATE ? 4u : 8u) : 0x80000000u;
+                if (GATE) {
+                    const uint32_t o = pack_bf16(pk_gelu(acc[nt][0] + bias[0]) * (acc[nt][1] + bias[1]),
+                                                 pk_gelu(acc[nt][2] + bias[2]) * (acc[nt][3] + bias[3]));
+                    __builtin_amdgcn_raw_buffer_store_b32(o, yr, vo, 0, 0);
+                } else {
+                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                    u32x2 o;
+                    o[0] = pack_bf16(acc[nt][0] + bias[0], acc[nt][1] + bias[1]);
+                    o[1] = pack_bf16(acc[nt][2] + bias[2], acc[nt][3] + bias[3]);
+                    __builtin_amdgcn_raw_buffer_store_b64(o, yr, vo, 0, 0);
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
     bf16x8 xa[KS][2], xb[KS][2];
-    const int r0 = y_begin - 1;
     xload(xa, r0); xload(xb, r0 + 1);
     gemm_row(xa, r0); gemm_row(xb, r0 + 1);
     xload(xa, r0 + 2); xload(xb, r0 + 3);
+    gemm_row(xa, r0 + 2); gemm_row(xb, r0 + 3);                      // (r0 + 3 <= y_end: ranges have at least 2 rows)
+    xload(xa, y_begin + 3); xload(xb, y_begin + 4);                  // (clamped rows past the range are never used)
     for (int y = y_begin; y < y_end; y += 2) {
-        gemm_row(xa, y + 1); gemm_row(xb, y + 2);
-        if (y + 2 < y_end) { xload(xa, y + 3); xload(xb, y + 4); }       // lands during phase D
-        __syncthreads();
         dw_rows(y);
-        __syncthreads();
+        if (y + 3 <= y_end) gemm_row(xa, y + 3);                     // rows y-1, y of the ring are free now
+        if (y + 4 <= y_end) gemm_row(xb, y + 4);
+        if (y + 5 <= y_end) xload(xa, y + 5);                        // land during the next D
+        if (y + 6 <= y_end) xload(xb, y + 6);
     }
 }
 
@@ -937,37 +994,45 @@ int pwdw_pk_launch(PwDwPk g, hipStream_t stream) {
     RST_REQUIRE(aligned16(g.A) && aligned16(g.X) && aligned16(g.Y) && aligned16(g.dww), "bf16 fused 1x1 + depthwise: operands must be 16-byte aligned");
     RST_REQUIRE(g.B <= 65535, "bf16 fused 1x1 + depthwise: batch %d exceeds 65535", g.B);
     {
-        // the ring form: all channels in one block, 32-column strips; LDS = weights + constants + 4 rows of chunks
-        const int npairs = (int)cdiv(g.Mb, 4), cbw = (int)cdiv(g.Mb, 8);        // 8 waves per block
-        const size_t lds = (size_t)npairs * 2 * KS * 1024 + (size_t)npairs * 32 * 2 * sizeof(float) + (size_t)4 * g.Mb * 32 * 16;
-        // not routed by default: the two barrier-separated phases expose their latencies (qkv product at
-        // 16 x 96 x 256^2: 469 us against 398 us for the register form and 420 us for the two kernels; 16 x 48 x 256^2:
-        // 268 against 212 us).  RST_BF16_RING=1 selects it (tests)
-        static const int ring_mode = getenv("RST_BF16_RING") ? atoi(getenv("RST_BF16_RING")) : 0;
-        if (ring_mode && lds <= 160 * 1024 && cbw <= 5 && g.H >= 2) {
-            static bool attr_done = false;
-            if (!attr_done) {
-#define RING_ATTR(ks, cw, gt) RST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pwdw_ring_kernel<ks, cw, gt, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
-                RING_ATTR(2, 3, false); RING_ATTR(2, 2, true); RING_ATTR(3, 5, false); RING_ATTR(3, 4, true);
-#undef RING_ATTR
-                attr_done = true;
+        // the ring form.  RST_BF16_RING=0 keeps the register form below (tests, A/B runs); RST_BF16_RING_NWB sets
+        // the waves (= pairs of row tiles) per block
+        static const int ring_mode = getenv("RST_BF16_RING") ? atoi(getenv("RST_BF16_RING")) : 1;
+        static const int ring_nwb = getenv("RST_BF16_RING_NWB") ? atoi(getenv("RST_BF16_RING_NWB")) : 0;
+        if (ring_mode && g.H >= 2 && (int64_t)g.H * g.W < (1ll << 27)) {
+            const int npairs = (int)cdiv(g.Mb, 4);
+            // waves per block: 2 to 4 (several blocks share a CU), the count that leaves the fewest idle waves
+            int nwb = 4;
+            if (ring_nwb > 0) {
+                nwb = ring_nwb > 8 ? 8 : ring_nwb;
+            } else {
+                int64_t waste = INT64_MAX;
+                for (int c = 4; c >= 2; --c) {
+                    const int64_t w_ = cdiv(npairs, c) * c - npairs;
+                    if (w_ < waste) { waste = w_; nwb = c; }
+                }
             }
-            g.rows = 32;
-            while (g.rows > 8 && (int64_t)cdiv(g.W, 30) * cdiv(g.H, g.rows) * g.B < 512) g.rows >>= 1;
-            const dim3 grid((unsigned)(cdiv(g.W, 30) * cdiv(g.H, g.rows)), 1, (unsigned)g.B);
+            const int ngroups = (int)cdiv(npairs, nwb);
+            nwb = (int)cdiv(npairs, ngroups);                       // even groups
+            static const int ring_rows = getenv("RST_BF16_RING_ROWS") ? atoi(getenv("RST_BF16_RING_ROWS")) : 32;
+            g.rows = ring_rows;
+            while (g.rows > 8 && (int64_t)cdiv(g.W, 30) * cdiv(g.H, g.rows) * g.B * ngroups * nwb < 256 * 8 * 2) g.rows >>= 1;
+            if (g.rows > g.H) g.rows = (int)round_up(g.H, 2);
+            const size_t lds = (size_t)(g.rows + 2) * 32 * 8 + (size_t)nwb * 128 * sizeof(float) + (size_t)nwb * 8192;
+            const dim3 grid((unsigned)(cdiv(g.W, 30) * cdiv(g.H, g.rows)), (unsigned)ngroups, (unsigned)g.B);
             const double px = (double)g.H * g.W * g.B;
             const double mout = g.gate ? g.Mb * 4 : g.Mb * 8;
             ProfScope prof(stream, g.gate ? "pk_pwdw_gate" : "pk_pwdw", px * g.Mb * 8 * (2.0 * g.Kb * 8 + 18.0), px * 2.0 * (g.Kb * 8 + mout));
-            bool launched = true;
-            if (KS == 2 && !g.gate && cbw <= 3) hipLaunchKernelGGL((pwdw_ring_kernel<2, 3, false, 8>), grid, dim3(512), lds, stream, g);
-            else if (KS == 2 && g.gate && cbw <= 2) hipLaunchKernelGGL((pwdw_ring_kernel<2, 2, true, 8>), grid, dim3(512), lds, stream, g);
-            else if (KS == 3 && !g.gate && cbw <= 5) hipLaunchKernelGGL((pwdw_ring_kernel<3, 5, false, 8>), grid, dim3(512), lds, stream, g);
-            else if (KS == 3 && g.gate && cbw <= 4) hipLaunchKernelGGL((pwdw_ring_kernel<3, 4, true, 8>), grid, dim3(512), lds, stream, g);
-            else launched = false;
-            if (launched) {
-                RST_LAUNCH_CHECK();
-                return RST_OK;
-            }
+            const void* kern = nullptr;
+#define RING_PICK(ks) (g.gate ? reinterpret_cast<const void*>(&pwdw_ring_kernel<ks, true>) : reinterpret_cast<const void*>(&pwdw_ring_kernel<ks, false>))
+            kern = KS == 1 ? RING_PICK(1) : KS == 2 ? RING_PICK(2) : RING_PICK(3);
+#undef RING_PICK
+            KernelSetup su;
+            RST_TRY(kernel_setup(kern, 512, 160 * 1024, &su));      // (the dynamic-LDS limit of the kernel: once, at its maximum)
+            PwDwPk gg = g;
+            void* args[] = {(void*)&gg, (void*)&nwb};
+            RST_HIP(hipLaunchKernel(kern, grid, dim3(64 * nwb), args, lds, stream));
+            RST_LAUNCH_CHECK();
+            return RST_OK;
         }
     }
     g.pb = gemm_pk_pairs(g.Kb, g.Mb);

@@ -305,7 +305,9 @@ bool gemm_f16s_supported(const GemmNN& g) {
     const bool strides4 = (g.N % 4 == 0) && (g.ldx % 4 == 0) && (g.x_s1 % 4 == 0) && (g.x_s2 % 4 == 0) &&
                           (g.ldy % 4 == 0) && (g.y_s1 % 4 == 0) && (g.y_s2 % 4 == 0) &&
                           (g.R == nullptr || ((g.ldr % 4 == 0) && (g.r_s1 % 4 == 0) && (g.r_s2 % 4 == 0)));
-    return al && strides4 && g.K % 2 == 0 && g.K >= 2 && (int64_t)g.nb1 * g.nb2 <= 65535;
+    // (an odd K is fine without a folded LayerNorm: the missing row re-reads row K - 1 against zero weights; the
+    // statistics of a folded LayerNorm mask channel pairs, so there K must be even)
+    return al && strides4 && (g.K % 2 == 0 || g.ln_mode == 0) && g.K >= 2 && (int64_t)g.nb1 * g.nb2 <= 65535;
 }
 
 int gemm_f16s_prep_launch(const float* w, int64_t w_bs, int nb, int lda, int transA, const float* gamma, const float* beta,
@@ -327,8 +329,8 @@ int gemm_f16s_launch(const GemmNN& g, hipStream_t stream) {
     RST_REQUIRE(g.X2 == nullptr || (g.ksplit > 0 && g.ksplit < g.K && g.ksplit % GF_BK == 0 && aligned16(g.X2) &&
                                     g.x2_s1 % 4 == 0 && g.x2_s2 % 4 == 0 && g.ln_mode == 0),
                 "gemm_f16s: the second input tensor needs a split at a multiple of 32 channels");
-    RST_REQUIRE(g.ln_mode == 0 || (g.ln_s && g.ln_c && g.R == nullptr && !g.accumulate && g.bias == nullptr),
-                "gemm_f16s: folded LayerNorm takes no residual / bias / accumulation");
+    RST_REQUIRE(g.ln_mode == 0 || (g.ln_s && g.ln_c && g.R == nullptr && !g.accumulate && g.bias == nullptr && g.K % 2 == 0),
+                "gemm_f16s: folded LayerNorm takes no residual / bias / accumulation and an even channel count");
     const int rt = gf_pick_rt(g.M);
     const int mblocks = (int)cdiv(g.M, 32 * rt), mtiles = (int)cdiv(g.M, 16), kch = (int)cdiv(g.K, 32);
     const int64_t gx = cdiv(g.N, GF_BN) * mblocks;

@@ -189,16 +189,17 @@ def test_prepared_weights_cache_follows_parameter_updates():
     assert torch.equal(changed.view(torch.int16), run(None).view(torch.int16))
 
 
-@pytest.mark.parametrize("switch", [{"RST_BF16_FUSE": "0"}, {"RST_BF16_FUSE": "2"}, {"RST_DW_MFMA": "3", "RST_BF16_FUSE": "0"},
-                                    {"RST_BF16_FUSE": "2", "RST_BF16_RING": "1"}, {"RST_DW_MFMA": "0", "RST_BF16_FUSE": "0"}],
-                         ids=["unfused", "fused_everywhere", "depthwise_on_matrix_pipe", "fused_through_lds_ring",
+@pytest.mark.parametrize("switch", [{"RST_BF16_FUSE": "0"}, {"RST_BF16_RING": "0"}, {"RST_DW_MFMA": "3", "RST_BF16_FUSE": "0"},
+                                    {"RST_BF16_RING_NWB": "8"}, {"RST_DW_MFMA": "0", "RST_BF16_FUSE": "0"}],
+                         ids=["unfused", "fused_in_registers", "depthwise_on_matrix_pipe", "ring_with_eight_waves",
                               "depthwise_on_vector_unit"])
 def test_block_with_kernel_variants_forced(switch):
-    """The fused 1x1 + depthwise kernel (intermediate in registers) is routed only where it was measured
-    faster.  RST_BF16_FUSE=2 forces it wherever it supports the shape (48 and 96 channels, plain and gated),
-    =0 switches it off; RST_DW_MFMA=3 runs both depthwise convolutions on the matrix pipe (dwm_pk_kernel, by default
-    only the gated one of small images), =0 none; RST_BF16_RING=1 takes the fused form that keeps the intermediate in an LDS row ring and
-    runs both stages on the matrix pipe (pwdw_ring_kernel, not routed by default).  The switches are read once per process, so the golden block cases re-run in a child."""
+    """By default the 1x1 + depthwise pairs of the 48- and 96-channel levels run fused, the intermediate in wave-private
+    LDS row rings and both stages on the matrix pipe (pwdw_ring_kernel).  RST_BF16_FUSE=0 switches the fusion off (1x1
+    kernel, then depthwise kernel); RST_BF16_RING=0 takes the fused form that keeps the intermediate in registers and runs
+    the taps on the vector unit; RST_BF16_RING_NWB=8 puts up to eight waves (pairs of row tiles) in a block instead of 2 to 4;
+    RST_DW_MFMA=3 runs both unfused depthwise convolutions on the matrix pipe (dwm_pk_kernel, by default only the gated one
+    of small images), =0 none.  The switches are read once per process, so the golden block cases re-run in a child."""
     import os
     import subprocess
     import sys
