@@ -11,6 +11,7 @@
 // ds_read_b64_tr_b16.
 #include "kernels.hpp"
 #include "bf16_common.hpp"
+#include <type_traits>
 
 namespace rst {
 
@@ -730,113 +731,88 @@ pwdw_pk_kernel(const PwDwPk g) {
 }
 
 // ---- fused 1x1 (folded LayerNorm) -> depthwise 3x3 (-> gate), both on the matrix pipe ----------------------
-// A block owns a strip of 32 columns (30 stored + the halo column on either side) and a range of rows; each of its
-// waves owns ONE pair of row tiles of the 1x1 product = 4 channel blocks of the intermediate, for the whole strip,
-// and walks down the rows on its own:
+// The work is cut into items (strip of 32 columns: 30 stored + the halo column on either side) x (range of rows) x
+// (ONE pair of row tiles of the 1x1 product = 4 channel blocks of the intermediate).  A wave takes one item and walks
+// down its rows on its own:
 //   G (row r): the 1x1 product of the row for the wave's pair (weights resident in registers, the pixel operand
-//     straight from memory, the next rows' already in flight), LayerNorm epilogue, zero outside the image, packed
-//     to bf16 chunks into the wave's PRIVATE ring of 4 rows in LDS -- written exactly as the depthwise
-//     convolution's B operand wants them;
+//     straight from memory, the next rows' already in flight); the LayerNorm statistics of the row's pixels on the
+//     matrix pipe as well (ones^T X: channel sums in every accumulator row; X^T X: sums of squares on the diagonal,
+//     handed to the other lane groups with one ds_bpermute -- bf16 products and fp32 sums, exact); LayerNorm
+//     epilogue, zero outside the image, packed to bf16 chunks into the wave's PRIVATE ring of 4 rows in LDS --
+//     written exactly as the depthwise convolution's B operand wants them;
 //   D (rows y, y+1): the depthwise convolution as in dwm_pk_kernel, its operand chunks read from the ring with
-//     ds_read_b128; the tap matrices (one non-zero per lane and k-step) are rebuilt from one register each.
-// A wave is the only producer and the only consumer of its ring, LDS operations of a wave complete in order, so
-// the row loop has NO barrier: the waves of a CU drift apart and fill each other's latencies.  The intermediate
-// never leaves the CU, nothing is unpacked, and the vector unit only runs the two epilogues.  What the waves share
-// are the LayerNorm statistics of the strip's rows: taken once per block in a prologue (on the matrix pipe as well),
-// kept in LDS, one barrier.
-// grid = (strips * row ranges, groups of `nwb` pairs, samples), nwb <= 8 waves per block
+//     ds_read_b128; the tap matrices have one non-zero per lane and k-step.
+// A wave is the only producer and the only consumer of its ring and LDS operations of a wave complete in order, so
+// the kernel has NO barrier and the waves share nothing: they drift apart and fill each other's latencies.  The
+// intermediate never leaves the CU, nothing is unpacked, and the vector unit only runs the two epilogues.
+// The vector unit is what bounds the loop, so it carries no address arithmetic: loads and stores go through buffer
+// descriptors (lane-constant offset + one scalar or vector row offset, out-of-range lanes dropped by the
+// descriptor instead of a branch), the row range starts at a multiple of 4 and the loop is unrolled by two, so that
+// every ring slot is a compile-time constant.
+// grid = (blocks of 4 items, 1, samples); blocks 8 apart share an XCD (and its L2) and take neighbouring items, so
+// that the pairs of one strip read its input from memory once.  g.rows % 4 == 0.
 template <int KS, bool GATE>
-__global__ void __launch_bounds__(512)
-pwdw_ring_kernel(const PwDwPk g, int nwb) {
-    constexpr int TW = 32;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* stat = reinterpret_cast<float2*>(smem);                                  // [rows + 2][TW]: mean (or 0), 1/sigma
-    float* sc = reinterpret_cast<float*>(smem + (size_t)(g.rows + 2) * TW * 8);      // [2][nwb * 32]
-    float* dbias = sc + 2 * nwb * 32;                                                // [nwb][4 blocks][16]: depthwise bias of accumulator row 4 gq + r
-    char* ring_all = reinterpret_cast<char*>(dbias + nwb * 64);                      // [nwb][4 rows][4 blocks][TW] chunks
+__global__ void __launch_bounds__(256, 2)
+pwdw_ring_kernel(const PwDwPk g) {
+    constexpr int TW = 32, SLOT = 4 * TW * 16;                       // bytes of a ring row (4 channel blocks)
+    __shared__ __attribute__((aligned(16))) char ring_all[4][4 * SLOT];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // (uniform: the store descriptors are built from it)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // (uniform: the descriptors are built from it)
     const int n_ = lane & 15, gq = lane >> 4;
     const int b = blockIdx.z;
     const int Mb = g.Mb, npairs = (Mb + 3) / 4;
-    const int pair = blockIdx.y * nwb + wave;
     const int H = g.H, W = g.W, Kb = g.Kb;
     const int64_t N = (int64_t)H * W;
     const int nstrips = (W + 29) / 30;
-    const int strip = blockIdx.x % nstrips, range = blockIdx.x / nstrips;
+    const int ntiles = nstrips * ((H + g.rows - 1) / g.rows);
+    // item of this wave: the blocks of an XCD (ids 8 apart) walk through a contiguous eighth of the items
+    const int per_xcd = gridDim.x >> 3;
+    const int vblock = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const int item = vblock * 4 + wave;
+    if (item >= ntiles * npairs) return;                             // (no barrier anywhere)
+    const int tile = item / npairs, pair = item % npairs;
+    const int strip = tile % nstrips, range = tile / nstrips;
     const int x0 = strip * 30 - 1;                                   // image column of strip column 0
     const int y_begin = range * g.rows;
     const int y_end = y_begin + g.rows < H ? y_begin + g.rows : H;
     const int r0 = y_begin - 1;
-    const bf16x8* Xp = reinterpret_cast<const bf16x8*>(g.X + (int64_t)b * g.x_bs);
     char* Yb = reinterpret_cast<char*>(g.Y + (int64_t)b * g.y_bs);
-    char* myring = ring_all + (size_t)wave * (4 * 4 * TW * 16);
+    char* myring = ring_all[wave];
     {
         const u32x4 z = {0u, 0u, 0u, 0u};                           // rows a short range never writes must stay finite
 #pragma unroll
         for (int i = 0; i < 8; ++i) reinterpret_cast<u32x4*>(myring)[i * 64 + lane] = z;
-        for (int i = tid; i < nwb * 32; i += 64 * nwb) {
-            const int p = blockIdx.y * nwb * 32 + i;
-            sc[i] = p < npairs * 32 ? g.ln_s[p] : 0.f;
-            sc[nwb * 32 + i] = p < npairs * 32 ? g.ln_c[p] : 0.f;
-        }
     }
-    // clamped column of strip column 16 nt + n_, and the chunk offsets of this lane's KS channel blocks
-    int xc[2]; bool x_in[2];
+    // the sample's input through a buffer descriptor: lane-constant offset of (channel block, clamped column), the
+    // clamped row as the scalar offset.  Channel blocks past Kb read block 0: the weights of those positions are zero,
+    // so the product ignores them and nothing has to wait for the load to mask it (the statistics mask them).
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(g.X + (int64_t)b * g.x_bs), 0, (int)__builtin_amdgcn_readfirstlane((int)((int64_t)Kb * N * 16)), 0x00020000);
+    bool x_in[2];
+    unsigned xoff[KS][2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int x = x0 + 16 * nt + n_;
-        xc[nt] = x < 0 ? 0 : (x < W ? x : W - 1);
+        const int xc = x < 0 ? 0 : (x < W ? x : W - 1);
         x_in[nt] = x >= 0 && x < W;
-    }
-    // (channel blocks past Kb read block 0: the weights of those positions are zero, so the product ignores them and
-    // nothing has to wait for the load to mask it; the statistics mask them)
-    auto xchunk = [&](int ks, int ry, int nt) -> bf16x8 {
-        const int yc = ry < 0 ? 0 : (ry < H ? ry : H - 1);
-        const int cb = 4 * ks + gq;
-        return Xp[(int64_t)(cb < Kb ? cb : 0) * N + (int64_t)yc * W + xc[nt]];
-    };
-    // ---- LayerNorm statistics of rows r0 .. y_end of the strip: task = (row, half of the strip), four in flight ----
-    {
-        const float invK = 1.0f / (float)g.K;
-        const u32x4 ones_w = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-        const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_w);
-        const int ntask = 2 * (y_end - r0 + 1);
-        for (int t0 = wave; t0 < ntask; t0 += 4 * nwb) {
-            bf16x8 xs[4][KS];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int t = t0 + u * nwb < ntask ? t0 + u * nwb : t0;
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) xs[u][ks] = xchunk(ks, r0 + (t >> 1), t & 1);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                // on the matrix pipe, exactly (bf16 products, fp32 sums): ones^T X gives the channel sum of pixel n_
-                // in every accumulator row, X^T X the sum of squares on its diagonal (row n_ = lane group n_ / 4)
-                const int t = t0 + u * nwb;
-                f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-                    const bf16x8 xv = 4 * ks + gq < Kb ? xs[u][ks] : z;
-                    a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xv, a1, 0, 0, 0);
-                    a2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xv, xv, a2, 0, 0, 0);
-                }
-                const int rsel = n_ & 3;
-                const float s1 = a1[0];
-                const float s2 = rsel == 0 ? a2[0] : rsel == 1 ? a2[1] : rsel == 2 ? a2[2] : a2[3];
-                const float m = s1 * invK;
-                const float var = fmaxf(s2 * invK - m * m, 0.f);
-                if (gq == (n_ >> 2) && t < ntask) stat[(t >> 1) * TW + 16 * (t & 1) + n_] = float2{g.ln_mode == 1 ? m : 0.f, 1.0f / sqrtf(var + 1e-5f)};
-            }
+        for (int ks = 0; ks < KS; ++ks) {
+            const int cb = 4 * ks + gq;
+            xoff[ks][nt] = (unsigned)(((int64_t)(cb < Kb ? cb : 0) * N + xc) * 16);
         }
     }
-    __syncthreads();
-    if (pair >= npairs) return;                                      // (no barrier below)
+    auto xload = [&](u32x4 (&dst)[KS][2], int ry) {
+        const int yc = ry < 0 ? 0 : (ry < H ? ry : H - 1);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) dst[ks][nt] = __builtin_amdgcn_raw_buffer_load_b128(xr, xoff[ks][nt], yc * W * 16, 0);
+    };
+    u32x4 xa[KS][2], xb[KS][2];
+    xload(xa, r0); xload(xb, r0 + 1);                                // in flight during the set-up below
 
     auto pos_of = [](int q) { return GATE ? ((q & 1) ? 4 + (q >> 1) : (q >> 1)) : q; };
-    // weights of the pair: [half][k-step]
+    // weights of the pair: [half][k-step]; LayerNorm constants of the lane's 8 channels
     bf16x8 wa[2][KS];
     {
         const bf16x8* Ap = reinterpret_cast<const bf16x8*>(g.A) + (size_t)pair * 2 * KS * 64 + lane;
@@ -845,143 +821,172 @@ pwdw_ring_kernel(const PwDwPk g, int nwb) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) wa[h][ks] = Ap[(h * KS + ks) * 64];
     }
+    const f32x4 sa = *reinterpret_cast<const f32x4*>(g.ln_s + pair * 32 + gq * 8), sb = *reinterpret_cast<const f32x4*>(g.ln_s + pair * 32 + gq * 8 + 4);
+    const f32x4 ca = *reinterpret_cast<const f32x4*>(g.ln_c + pair * 32 + gq * 8), cc4 = *reinterpret_cast<const f32x4*>(g.ln_c + pair * 32 + gq * 8 + 4);
     // taps of the wave's 4 channel blocks as in dwm_pk_kernel: this lane is matrix row m = n_, k-group gq; its one
-    // non-zero of k-step s3 sits in 32-bit word kq of the fragment
+    // non-zero of k-step s3 sits in 32-bit word kq of the fragment.  Biases of the lane's 4 accumulator rows.
     const int kq = pos_of(n_ & 7) >> 1;
-    uint32_t tapv[4][3];
+    bf16x8 af[4][3];
+    f32x4 dbias[4];
+    __amdgpu_buffer_rsrc_t yr[4];
+    bool st_ok[4][2];
+    const int plane_bytes = (int)__builtin_amdgcn_readfirstlane((int)(N * 16 - (GATE ? 8 : 0)));      // (N < 2^27: checked by the launcher)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int cb = 4 * pair + j;
-        const float* wl = g.dww + (cb < Mb ? cb : 0) * 80;
+        // (a channel block past Mb -- the last pair may be partial -- is computed on its all-zero ring rows and
+        // dropped by the stores: no branch, every path issues the same number of memory operations)
+        const bool cb_live = 4 * pair + j < Mb;
+        const int cb = cb_live ? 4 * pair + j : Mb - 1;
+        const float* wl = g.dww + cb * 80;
         const int orow = n_ >> 3, p = pos_of(n_ & 7);
 #pragma unroll
         for (int s3 = 0; s3 < 3; ++s3) {
             const int t = 4 * s3 + gq, i = t / 3, d = t % 3, dy = i - orow;
             const float wr = wl[((dy < 0 ? 0 : (dy > 2 ? 2 : dy)) * 3 + d) * 8 + p];      // (no branch around the load)
             const uint32_t bits = to_bf16_bits((dy >= 0 && dy <= 2) ? wr : 0.f);
-            tapv[j][s3] = (p & 1) ? (bits << 16) : bits;
+            const uint32_t tv = (p & 1) ? (bits << 16) : bits;
+            u32x4 f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) f[k] = kq == k ? tv : 0u;
+            af[j][s3] = __builtin_bit_cast(bf16x8, f);
         }
-        if (n_ < 4) dbias[(wave * 4 + j) * 16 + 4 * gq + n_] = wl[72 + pos_of((4 * gq + n_) & 7)];      // (read by this wave only)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dbias[j][r] = wl[72 + pos_of((4 * gq + r) & 7)];
+        // stores through a buffer descriptor over the channel block's plane: lanes outside the strip, the image or
+        // the row range get an offset past its end and are dropped
+        yr[j] = __builtin_amdgcn_make_buffer_rsrc(
+            Yb + (GATE ? ((int64_t)(cb >> 1) * N * 16 + (cb & 1) * 8) : (int64_t)cb * N * 16), 0, plane_bytes, 0x00020000);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int col = 16 * nt + n_;
+            st_ok[j][nt] = cb_live && col >= 1 && col <= 30 && x0 + col < W;
+        }
     }
-    // ring offsets of this lane's three operand chunks (k-step s3 -> slot 4 s3 + gq -> row offset, column)
-    int drow[3], dcol[3][2];
+    unsigned st_col[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) st_col[nt] = (unsigned)(x0 + 16 * nt + n_) * 16u + (unsigned)(gq & 1) * (GATE ? 4u : 8u);
+    // LDS addresses of this lane's operand chunks: k-step s3 -> slot 4 s3 + gq -> (row offset, column); the ring row
+    // of image row y + dr is (y + dr) & 3 and y % 4 is 0 (PAR 0) or 2 (PAR 1)
+    const char* dsrc[2][3][2];
 #pragma unroll
     for (int s3 = 0; s3 < 3; ++s3) {
-        const int t = 4 * s3 + gq;
-        drow[s3] = t / 3 - 1;
+        const int t = 4 * s3 + gq, dr = t / 3 - 1;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int c = 16 * nt + n_ + t % 3 - 1;
-            dcol[s3][nt] = (c < 0 ? 0 : (c < TW ? c : TW - 1)) * 16;   // only the unstored halo columns clamp
+            const int cc = c < 0 ? 0 : (c < TW ? c : TW - 1);          // only the unstored halo columns clamp
+#pragma unroll
+            for (int par = 0; par < 2; ++par) dsrc[par][s3][nt] = myring + ((2 * par + dr) & 3) * SLOT + cc * 16;
         }
     }
-    const f32x4* sp = reinterpret_cast<const f32x4*>(sc + wave * 32 + gq * 8);
-    const f32x4* cp = reinterpret_cast<const f32x4*>(sc + nwb * 32 + wave * 32 + gq * 8);
+    char* gdst = myring + gq * (TW * 16) + n_ * 16;                  // + slot * SLOT + nt * 256
     const bool cb_ok = 4 * pair + gq < Mb;
-    const int plane_bytes = (int)__builtin_amdgcn_readfirstlane((int)(N * 16 - (GATE ? 8 : 0)));      // (N < 2^27: checked by the launcher)
+    const float invK = 1.0f / (float)g.K;
+    const bool with_mean = g.ln_mode == 1;
+    const u32x4 ones_w = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones_w);
+    const int diag_lane = ((n_ >> 2) * 16 + n_) * 4;                 // byte index of the lane that holds pixel n_'s diagonal entry
+    const int rsel = n_ & 3;
+    const bool kmask = Kb % 4 != 0;                                  // the last k-step has channel blocks past Kb
 
-    auto xload = [&](bf16x8 (&dst)[KS][2], int ry) {
+    // G: row ry of the intermediate for the wave's 4 channel blocks -> ring row `slot`
+    auto gemm_row = [&](const u32x4 (&xf)[KS][2], int ry, int slot) {
+        f32x4 acc[2][2], a1[2], a2[2];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) dst[ks][nt] = xchunk(ks, ry, nt);
-    };
-    // G: row ry of the intermediate for the wave's 4 channel blocks -> ring
-    auto gemm_row = [&](const bf16x8 (&xf)[KS][2], int ry) {
-        f32x4 acc[2][2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) acc[h][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < 2; ++nt) {
+            acc[0][nt] = acc[1][nt] = a1[nt] = a2[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0][ks], xf[ks][nt], acc[0][nt], 0, 0, 0);
-                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1][ks], xf[ks][nt], acc[1][nt], 0, 0, 0);
+                const bf16x8 xv = __builtin_bit_cast(bf16x8, xf[ks][nt]);
+                acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[0][ks], xv, acc[0][nt], 0, 0, 0);
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[1][ks], xv, acc[1][nt], 0, 0, 0);
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                const bf16x8 xm = (ks == KS - 1 && kmask) ? __builtin_bit_cast(bf16x8, 4 * ks + gq < Kb ? xf[ks][nt] : z) : xv;
+                a1[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, xm, a1[nt], 0, 0, 0);
+                a2[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xm, xm, a2[nt], 0, 0, 0);
             }
-        const f32x4 sa = sp[0], sb = sp[1], ca = cp[0], cc = cp[1];
         const bool row_in = ry >= 0 && ry < H;
-        char* rrow = myring + (size_t)(((ry & 3) * 4 + gq) * TW) * 16;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const float2 st = stat[(ry - r0) * TW + 16 * nt + n_];
+            const float dsel = rsel == 0 ? a2[nt][0] : rsel == 1 ? a2[nt][1] : rsel == 2 ? a2[nt][2] : a2[nt][3];
+            const float s2 = __int_as_float(__builtin_amdgcn_ds_bpermute(diag_lane, __float_as_int(dsel)));
+            const float m = a1[nt][0] * invK;
+            const float var = fmaxf(s2 * invK - m * m, 0.f);
+            const float rstd = __builtin_amdgcn_rsqf(var + 1e-5f);       // (1 ulp; the result is rounded to bf16)
+            const float nm = with_mean ? -m : 0.f;
             float v[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                v[r] = fmaf(fmaf(-st.x, sa[r], acc[0][nt][r]), st.y, ca[r]);
-                v[4 + r] = fmaf(fmaf(-st.x, sb[r], acc[1][nt][r]), st.y, cc[r]);
+                v[r] = fmaf(fmaf(nm, sa[r], acc[0][nt][r]), rstd, ca[r]);
+                v[4 + r] = fmaf(fmaf(nm, sb[r], acc[1][nt][r]), rstd, cc4[r]);
             }
             const u32x4 z = {0u, 0u, 0u, 0u};
-            if (cb_ok) *reinterpret_cast<u32x4*>(rrow + (16 * nt + n_) * 16) = (row_in && x_in[nt]) ? pack8(v) : z;
+            *reinterpret_cast<u32x4*>(gdst + slot * SLOT + nt * 256) = (cb_ok && row_in && x_in[nt]) ? pack8(v) : z;
         }
     };
-    // D: output rows y, y + 1 (the ring holds rows y-1 .. y+2); one channel block at a time, so that few operand
-    // chunks are live at once (the other waves of the SIMD cover the LDS latency)
-    auto dw_rows = [&](int y) {
-        const char* rbase[3];
+    // D: output rows y, y + 1 (the ring holds rows y-1 .. y+2)
+    auto dw_rows = [&](int y, auto Par) {
+        constexpr int PAR = decltype(Par)::value;
+        const int yo = y + (gq >> 1);
+        const unsigned rowoff = (unsigned)(yo * W) * 16u;
+        const bool row_ok = yo < y_end;
+        // the operand chunks of channel block j + 1 are requested before the products of block j start (the scheduling
+        // barrier keeps the compiler from sinking each read next to its use, where every product would wait out the
+        // LDS latency)
+        u32x4 bw[2][3][2];
+        auto fetch = [&](u32x4 (&dst)[3][2], int j) {
 #pragma unroll
-        for (int s3 = 0; s3 < 3; ++s3) rbase[s3] = myring + (size_t)(((y + drow[s3]) & 3) * 4 * TW) * 16;
+            for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)      // (read with the type the ring is written with: the compiler must see that these alias)
+                    dst[s3][nt] = *reinterpret_cast<const u32x4*>(dsrc[PAR][s3][nt] + j * (TW * 16));
+        };
+        fetch(bw[0], 0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            // (a channel block past Mb -- the last pair may be partial -- is computed on its all-zero ring rows and
-            // dropped by the stores: no branch, every path issues the same number of memory operations)
-            const int cb = 4 * pair + j < Mb ? 4 * pair + j : Mb - 1;
-            const bool cb_live = 4 * pair + j < Mb;
+            if (j < 3) fetch(bw[(j + 1) & 1], j + 1);
+            __builtin_amdgcn_sched_barrier(0);
             f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-            for (int s3 = 0; s3 < 3; ++s3) {
-                u32x4 f;
+            for (int s3 = 0; s3 < 3; ++s3)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) f[k] = kq == k ? tapv[j][s3] : 0u;
-                const bf16x8 af = __builtin_bit_cast(bf16x8, f);
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    // (read with the type the ring is written with: the compiler must see that these alias)
-                    const u32x4 bw = *reinterpret_cast<const u32x4*>(rbase[s3] + j * (TW * 16) + dcol[s3][nt]);
-                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, __builtin_bit_cast(bf16x8, bw), acc[nt], 0, 0, 0);
-                }
-            }
-            const f32x4 bias = *reinterpret_cast<const f32x4*>(dbias + (wave * 4 + j) * 16 + 4 * gq);
-            const int yo = y + (gq >> 1);
-            // stores through a buffer descriptor over the channel block's plane: lanes outside the strip, the image or
-            // the row range get an offset past its end and are dropped -- no branch, so the compiler can count the
-            // stores and the next G waits for its operand loads only
-            const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(
-                Yb + (GATE ? ((int64_t)(cb >> 1) * N * 16 + (cb & 1) * 8) : (int64_t)cb * N * 16), 0, plane_bytes, 0x00020000);
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j][s3], __builtin_bit_cast(bf16x8, bw[j & 1][s3][nt]), acc[nt], 0, 0, 0);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                const int col = 16 * nt + n_, x = x0 + col;
-                const bool ok = cb_live && col >= 1 && col <= 30 && x < W && yo < y_end;
-                const unsigned vo = ok ? (unsigned)(yo * W + x) * 16u + (unsigned)(gq & 1) * (GATE ? 4u : 8u) : 0x80000000u;
+                const unsigned vo = (st_ok[j][nt] && row_ok) ? rowoff + st_col[nt] : 0x80000000u;
                 if (GATE) {
-                    const uint32_t o = pack_bf16(pk_gelu(acc[nt][0] + bias[0]) * (acc[nt][1] + bias[1]),
-                                                 pk_gelu(acc[nt][2] + bias[2]) * (acc[nt][3] + bias[3]));
-                    __builtin_amdgcn_raw_buffer_store_b32(o, yr, vo, 0, 0);
+                    const uint32_t o = pack_bf16(pk_gelu(acc[nt][0] + dbias[j][0]) * (acc[nt][1] + dbias[j][1]),
+                                                 pk_gelu(acc[nt][2] + dbias[j][2]) * (acc[nt][3] + dbias[j][3]));
+                    __builtin_amdgcn_raw_buffer_store_b32(o, yr[j], vo, 0, 0);
                 } else {
                     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
                     u32x2 o;
-                    o[0] = pack_bf16(acc[nt][0] + bias[0], acc[nt][1] + bias[1]);
-                    o[1] = pack_bf16(acc[nt][2] + bias[2], acc[nt][3] + bias[3]);
-                    __builtin_amdgcn_raw_buffer_store_b64(o, yr, vo, 0, 0);
+                    o[0] = pack_bf16(acc[nt][0] + dbias[j][0], acc[nt][1] + dbias[j][1]);
+                    o[1] = pack_bf16(acc[nt][2] + dbias[j][2], acc[nt][3] + dbias[j][3]);
+                    __builtin_amdgcn_raw_buffer_store_b64(o, yr[j], vo, 0, 0);
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    bf16x8 xa[KS][2], xb[KS][2];
-    xload(xa, r0); xload(xb, r0 + 1);
-    gemm_row(xa, r0); gemm_row(xb, r0 + 1);
+    gemm_row(xa, r0, 3); gemm_row(xb, r0 + 1, 0);
     xload(xa, r0 + 2); xload(xb, r0 + 3);
-    gemm_row(xa, r0 + 2); gemm_row(xb, r0 + 3);                      // (r0 + 3 <= y_end: ranges have at least 2 rows)
+    gemm_row(xa, r0 + 2, 1); gemm_row(xb, r0 + 3, 2);               // (a row past y_end is past the image: written as zeros)
     xload(xa, y_begin + 3); xload(xb, y_begin + 4);                  // (clamped rows past the range are never used)
-    for (int y = y_begin; y < y_end; y += 2) {
-        dw_rows(y);
-        if (y + 3 <= y_end) gemm_row(xa, y + 3);                     // rows y-1, y of the ring are free now
-        if (y + 4 <= y_end) gemm_row(xb, y + 4);
-        if (y + 5 <= y_end) xload(xa, y + 5);                        // land during the next D
-        if (y + 6 <= y_end) xload(xb, y + 6);
+    auto step = [&](int y, auto Par) {
+        constexpr int PAR = decltype(Par)::value;
+        dw_rows(y, Par);
+        if (y + 3 <= y_end) gemm_row(xa, y + 3, (2 * PAR + 3) & 3);  // rows y-1, y of the ring are free now
+        if (y + 4 <= y_end) gemm_row(xb, y + 4, (2 * PAR) & 3);
+        xload(xa, y + 5); xload(xb, y + 6);                          // land during the next D
+    };
+    for (int y = y_begin; y < y_end; y += 4) {
+        step(y, std::integral_constant<int, 0>{});
+        if (y + 2 < y_end) step(y + 2, std::integral_constant<int, 1>{});
     }
 }
 
@@ -994,43 +999,27 @@ int pwdw_pk_launch(PwDwPk g, hipStream_t stream) {
     RST_REQUIRE(aligned16(g.A) && aligned16(g.X) && aligned16(g.Y) && aligned16(g.dww), "bf16 fused 1x1 + depthwise: operands must be 16-byte aligned");
     RST_REQUIRE(g.B <= 65535, "bf16 fused 1x1 + depthwise: batch %d exceeds 65535", g.B);
     {
-        // the ring form.  RST_BF16_RING=0 keeps the register form below (tests, A/B runs); RST_BF16_RING_NWB sets
-        // the waves (= pairs of row tiles) per block
+        // the ring form.  RST_BF16_RING=0 keeps the register form below (tests, A/B runs)
         static const int ring_mode = getenv("RST_BF16_RING") ? atoi(getenv("RST_BF16_RING")) : 1;
-        static const int ring_nwb = getenv("RST_BF16_RING_NWB") ? atoi(getenv("RST_BF16_RING_NWB")) : 0;
-        if (ring_mode && g.H >= 2 && (int64_t)g.H * g.W < (1ll << 27)) {
+        if (ring_mode && g.H >= 2 && (int64_t)g.H * g.W < (1ll << 27) && (int64_t)g.Kb * g.H * g.W * 16 < (1ll << 31)) {
             const int npairs = (int)cdiv(g.Mb, 4);
-            // waves per block: 2 to 4 (several blocks share a CU), the count that leaves the fewest idle waves
-            int nwb = 4;
-            if (ring_nwb > 0) {
-                nwb = ring_nwb > 8 ? 8 : ring_nwb;
-            } else {
-                int64_t waste = INT64_MAX;
-                for (int c = 4; c >= 2; --c) {
-                    const int64_t w_ = cdiv(npairs, c) * c - npairs;
-                    if (w_ < waste) { waste = w_; nwb = c; }
-                }
-            }
-            const int ngroups = (int)cdiv(npairs, nwb);
-            nwb = (int)cdiv(npairs, ngroups);                       // even groups
+            // rows per item: long ranges recompute fewer halo rows; short ones give the chip enough waves
             static const int ring_rows = getenv("RST_BF16_RING_ROWS") ? atoi(getenv("RST_BF16_RING_ROWS")) : 32;
-            g.rows = ring_rows;
-            while (g.rows > 8 && (int64_t)cdiv(g.W, 30) * cdiv(g.H, g.rows) * g.B * ngroups * nwb < 256 * 8 * 2) g.rows >>= 1;
-            if (g.rows > g.H) g.rows = (int)round_up(g.H, 2);
-            const size_t lds = (size_t)(g.rows + 2) * 32 * 8 + (size_t)nwb * 128 * sizeof(float) + (size_t)nwb * 8192;
-            const dim3 grid((unsigned)(cdiv(g.W, 30) * cdiv(g.H, g.rows)), (unsigned)ngroups, (unsigned)g.B);
+            g.rows = ring_rows >= 4 ? ring_rows / 4 * 4 : 32;
+            while (g.rows > 8 && (int64_t)cdiv(g.W, 30) * cdiv(g.H, g.rows) * g.B * npairs < 256 * 8 * 2) g.rows >>= 1;
+            if (g.rows > g.H) g.rows = (int)round_up(g.H, 4);
+            const int64_t items = cdiv(g.W, 30) * cdiv(g.H, g.rows) * npairs;
+            const dim3 grid((unsigned)round_up(cdiv(items, 4), 8), 1, (unsigned)g.B);
             const double px = (double)g.H * g.W * g.B;
             const double mout = g.gate ? g.Mb * 4 : g.Mb * 8;
             ProfScope prof(stream, g.gate ? "pk_pwdw_gate" : "pk_pwdw", px * g.Mb * 8 * (2.0 * g.Kb * 8 + 18.0), px * 2.0 * (g.Kb * 8 + mout));
-            const void* kern = nullptr;
-#define RING_PICK(ks) (g.gate ? reinterpret_cast<const void*>(&pwdw_ring_kernel<ks, true>) : reinterpret_cast<const void*>(&pwdw_ring_kernel<ks, false>))
-            kern = KS == 1 ? RING_PICK(1) : KS == 2 ? RING_PICK(2) : RING_PICK(3);
-#undef RING_PICK
-            KernelSetup su;
-            RST_TRY(kernel_setup(kern, 512, 160 * 1024, &su));      // (the dynamic-LDS limit of the kernel: once, at its maximum)
-            PwDwPk gg = g;
-            void* args[] = {(void*)&gg, (void*)&nwb};
-            RST_HIP(hipLaunchKernel(kern, grid, dim3(64 * nwb), args, lds, stream));
+#define RING_GO(ks)                                                                                    \
+    do {                                                                                               \
+        if (g.gate) hipLaunchKernelGGL((pwdw_ring_kernel<ks, true>), grid, dim3(256), 0, stream, g);    \
+        else hipLaunchKernelGGL((pwdw_ring_kernel<ks, false>), grid, dim3(256), 0, stream, g);          \
+    } while (0)
+            if (KS == 1) RING_GO(1); else if (KS == 2) RING_GO(2); else RING_GO(3);
+#undef RING_GO
             RST_LAUNCH_CHECK();
             return RST_OK;
         }

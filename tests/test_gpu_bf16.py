@@ -190,14 +190,14 @@ def test_prepared_weights_cache_follows_parameter_updates():
 
 
 @pytest.mark.parametrize("switch", [{"RST_BF16_FUSE": "0"}, {"RST_BF16_RING": "0"}, {"RST_DW_MFMA": "3", "RST_BF16_FUSE": "0"},
-                                    {"RST_BF16_RING_NWB": "8"}, {"RST_DW_MFMA": "0", "RST_BF16_FUSE": "0"}],
-                         ids=["unfused", "fused_in_registers", "depthwise_on_matrix_pipe", "ring_with_eight_waves",
+                                    {"RST_BF16_RING_ROWS": "8"}, {"RST_DW_MFMA": "0", "RST_BF16_FUSE": "0"}],
+                         ids=["unfused", "fused_in_registers", "depthwise_on_matrix_pipe", "ring_with_short_row_ranges",
                               "depthwise_on_vector_unit"])
 def test_block_with_kernel_variants_forced(switch):
     """By default the 1x1 + depthwise pairs of the 48- and 96-channel levels run fused, the intermediate in wave-private
     LDS row rings and both stages on the matrix pipe (pwdw_ring_kernel).  RST_BF16_FUSE=0 switches the fusion off (1x1
     kernel, then depthwise kernel); RST_BF16_RING=0 takes the fused form that keeps the intermediate in registers and runs
-    the taps on the vector unit; RST_BF16_RING_NWB=8 puts up to eight waves (pairs of row tiles) in a block instead of 2 to 4;
+    the taps on the vector unit; RST_BF16_RING_ROWS=8 cuts the rows into ranges of 8 instead of 32 (more range borders);
     RST_DW_MFMA=3 runs both unfused depthwise convolutions on the matrix pipe (dwm_pk_kernel, by default only the gated one
     of small images), =0 none.  The switches are read once per process, so the golden block cases re-run in a child."""
     import os
