@@ -829,8 +829,8 @@ pwdw_ring_kernel(const PwDwPk g) {
     bf16x8 af[4][3];
     f32x4 dbias[4];
     __amdgpu_buffer_rsrc_t yr[4];
-    bool st_ok[4][2];
-    const int plane_bytes = (int)__builtin_amdgcn_readfirstlane((int)(N * 16 - (GATE ? 8 : 0)));      // (N < 2^27: checked by the launcher)
+    bool st_ok[4];
+    const int plane_bytes = (int)__builtin_amdgcn_readfirstlane((int)(N * 16));      // (N < 2^27: checked by the launcher)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         // (a channel block past Mb -- the last pair may be partial -- is computed on its all-zero ring rows and
@@ -854,17 +854,14 @@ pwdw_ring_kernel(const PwDwPk g) {
         for (int r = 0; r < 4; ++r) dbias[j][r] = wl[72 + pos_of((4 * gq + r) & 7)];
         // stores through a buffer descriptor over the channel block's plane: lanes outside the strip, the image or
         // the row range get an offset past its end and are dropped
-        yr[j] = __builtin_amdgcn_make_buffer_rsrc(
-            Yb + (GATE ? ((int64_t)(cb >> 1) * N * 16 + (cb & 1) * 8) : (int64_t)cb * N * 16), 0, plane_bytes, 0x00020000);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int col = 16 * nt + n_;
-            st_ok[j][nt] = cb_live && col >= 1 && col <= 30 && x0 + col < W;
+        yr[j] = __builtin_amdgcn_make_buffer_rsrc(Yb + (int64_t)(GATE ? cb >> 1 : cb) * N * 16, 0, plane_bytes, 0x00020000);
+        {
+            const int col = 16 * (gq & 1) + n_;
+            st_ok[j] = cb_live && col >= 1 && col <= 30 && x0 + col < W;
         }
     }
-    unsigned st_col[2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) st_col[nt] = (unsigned)(x0 + 16 * nt + n_) * 16u + (unsigned)(gq & 1) * (GATE ? 4u : 8u);
+    // after the exchange below a lane stores the whole chunk of strip column 16 (gq & 1) + n_ in row y + (gq >> 1)
+    const unsigned st_col = (unsigned)(x0 + 16 * (gq & 1) + n_) * 16u;
     // LDS addresses of this lane's operand chunks: k-step s3 -> slot 4 s3 + gq -> (row offset, column); the ring row
     // of image row y + dr is (y + dr) & 3 and y % 4 is 0 (PAR 0) or 2 (PAR 1)
     const char* dsrc[2][3][2];
@@ -944,6 +941,7 @@ pwdw_ring_kernel(const PwDwPk g) {
                 for (int nt = 0; nt < 2; ++nt)      // (read with the type the ring is written with: the compiler must see that these alias)
                     dst[s3][nt] = *reinterpret_cast<const u32x4*>(dsrc[PAR][s3][nt] + j * (TW * 16));
         };
+        uint32_t gate_lo[2], gate_hi[2];
         fetch(bw[0], 0);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -955,20 +953,34 @@ pwdw_ring_kernel(const PwDwPk g) {
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
                     acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[j][s3], __builtin_bit_cast(bf16x8, bw[j & 1][s3][nt]), acc[nt], 0, 0, 0);
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const unsigned vo = (st_ok[j][nt] && row_ok) ? rowoff + st_col[nt] : 0x80000000u;
-                if (GATE) {
-                    const uint32_t o = pack_bf16(pk_gelu(acc[nt][0] + dbias[j][0]) * (acc[nt][1] + dbias[j][1]),
-                                                 pk_gelu(acc[nt][2] + dbias[j][2]) * (acc[nt][3] + dbias[j][3]));
-                    __builtin_amdgcn_raw_buffer_store_b32(o, yr[j], vo, 0, 0);
-                } else {
-                    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-                    u32x2 o;
-                    o[0] = pack_bf16(acc[nt][0] + dbias[j][0], acc[nt][1] + dbias[j][1]);
-                    o[1] = pack_bf16(acc[nt][2] + dbias[j][2], acc[nt][3] + dbias[j][3]);
-                    __builtin_amdgcn_raw_buffer_store_b64(o, yr[j], vo, 0, 0);
+            // The lane holds 4 channels (8 bytes; gated: 2 products, 4 bytes) of pixel n_ in both halves of the strip;
+            // lane groups 2i and 2i+1 hold the two halves of the same chunks.  v_permlane16_swap hands the odd group's
+            // share of the left half to the even group and the even group's share of the right half to the odd one:
+            // every lane then stores one whole 16-byte chunk (gated: the 8 bytes of its channel block, and the two
+            // blocks of a chunk are the same lane's j and j + 1) -- half (a quarter) as many, wider stores.
+            if (GATE) {
+                const uint32_t o0 = pack_bf16(pk_gelu(acc[0][0] + dbias[j][0]) * (acc[0][1] + dbias[j][1]),
+                                              pk_gelu(acc[0][2] + dbias[j][2]) * (acc[0][3] + dbias[j][3]));
+                const uint32_t o1 = pack_bf16(pk_gelu(acc[1][0] + dbias[j][0]) * (acc[1][1] + dbias[j][1]),
+                                              pk_gelu(acc[1][2] + dbias[j][2]) * (acc[1][3] + dbias[j][3]));
+                const auto sw = __builtin_amdgcn_permlane16_swap(o0, o1, false, false);
+                gate_lo[j & 1] = sw[0]; gate_hi[j & 1] = sw[1];
+                if (j & 1) {
+                    // (the gated product has an even number of channel blocks: both blocks of a chunk are live together)
+                    const unsigned vo = (st_ok[j - 1] && row_ok) ? rowoff + st_col : 0x80000000u;
+                    const u32x4 o = {gate_lo[0], gate_hi[0], gate_lo[1], gate_hi[1]};
+                    __builtin_amdgcn_raw_buffer_store_b128(o, yr[j - 1], vo, 0, 0);
                 }
+            } else {
+                const uint32_t a0 = pack_bf16(acc[0][0] + dbias[j][0], acc[0][1] + dbias[j][1]);
+                const uint32_t a1 = pack_bf16(acc[0][2] + dbias[j][2], acc[0][3] + dbias[j][3]);
+                const uint32_t b0 = pack_bf16(acc[1][0] + dbias[j][0], acc[1][1] + dbias[j][1]);
+                const uint32_t b1 = pack_bf16(acc[1][2] + dbias[j][2], acc[1][3] + dbias[j][3]);
+                const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+                const unsigned vo = (st_ok[j] && row_ok) ? rowoff + st_col : 0x80000000u;
+                const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+                __builtin_amdgcn_raw_buffer_store_b128(o, yr[j], vo, 0, 0);
             }
         }
     };
