@@ -128,8 +128,11 @@ def test_model_bf16_end_to_end_psnr():
     assert torch.isfinite(out.float()).all()
     # a target at a realistic distance from the output (~30 dB)
     target = (ref + 0.03 * torch.randn(ref.shape, generator=g).cuda()).clamp(0, 1)
-    for o in (out.float(), out_ac):
-        assert abs(_psnr(o, target) - _psnr(ref, target)) < 0.01
+    # fp32 image out of the bf16 kernels: against the fp32 path.  bf16 image out: against the fp32 result held in the
+    # same container -- rounding an image in [0, 1] to bf16 is an error of 1.4e-3 rms by itself, 0.0095 dB at this
+    # distance from the target, whichever kernels produced the image
+    assert abs(_psnr(out_ac, target) - _psnr(ref, target)) < 0.01
+    assert abs(_psnr(out.float(), target) - _psnr(ref.bfloat16().float(), target)) < 0.01
     assert _maxrel(out_ac, ref) < BF16_TOL
 
 
@@ -214,7 +217,7 @@ def test_block_with_kernel_variants_forced(switch):
 
 def test_tiled_inference_bf16_close_to_fp32():
     """Tile-sharded inference takes the bf16 path tile by tile when the image is bf16: same tiling, outputs within
-    the bf16 tolerance of the fp32 tiles and the same PSNR against a target to 0.01 dB."""
+    the bf16 tolerance of the fp32 tiles and the same PSNR against a target to 0.01 dB as the fp32 result rounded to bf16."""
     import bench
     from superresolution_amd.parallel import tiled_inference
     net = bench.build_model(0).cuda().eval()
@@ -226,7 +229,8 @@ def test_tiled_inference_bf16_close_to_fp32():
     assert out.dtype == torch.bfloat16 and out.shape == ref.shape
     assert _maxrel(out.float(), ref) < BF16_TOL
     target = (ref + 0.03 * torch.randn(ref.shape, generator=g).cuda()).clamp(0, 1)
-    assert abs(_psnr(out.float(), target) - _psnr(ref, target)) < 0.01
+    # (the bf16 image against the fp32 result in the same container: see test_model_bf16_end_to_end_psnr)
+    assert abs(_psnr(out.float(), target) - _psnr(ref.bfloat16().float(), target)) < 0.01
 
 
 @pytest.mark.parametrize("shape", [(2, 48, 6, 10), (1, 96, 8, 4), (1, 8, 2, 2)])
