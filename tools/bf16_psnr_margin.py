@@ -1,5 +1,8 @@
+"""PSNR of the bf16 storage path against a synthetic target, next to the fp32 path's, for a few image shapes and the tiled
+route: how far the 0.01 dB end-to-end criterion is from what the path delivers (run on the GPU box:
+python tools/bf16_psnr_margin.py; RST_BF16_RING=0 / RST_BF16_FUSE=0 select the other kernel routes)."""
 import os, sys, torch
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from superresolution_amd.parallel import tiled_inference
 def psnr(a, b): return float(10 * torch.log10(1.0 / ((a.double() - b.double()) ** 2).mean()))
