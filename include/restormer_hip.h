@@ -353,6 +353,14 @@ int32_t rst_bf16_conv3x3_supported(int32_t Cin, int32_t Cout, int32_t H, int32_t
 int rst_bf16_conv3x3_fwd(const void* x_packed, const float* weight, const float* bias, void* y_packed,
                          int32_t B, int32_t Cin, int32_t Cout, int32_t H, int32_t W, int32_t shuffle_mode,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* The network's last layer on the bf16 storage path (model/Restromer.py:381-383,  */
+/* 420-431): nn.Conv2d(Cin, Cout, 3, padding=1) with at most 4 output channels on   */
+/* a packed bf16 input, fp32 weights and sums, fp32 NCHW result; plus `residual`     */
+/* ([B][Cout][H][W] fp32) or the bilinear x2 (align_corners=False) of `lowres`       */
+/* ([B][Cout][H/2][W/2] fp32), at most one of the two, either may be null.  W even.  */
+int32_t rst_bf16_conv3x3_fewout_fwd(const void* x_packed, const float* weight, const float* bias, const float* residual,
+                                    const float* lowres, float* y, int32_t B, int32_t Cin, int32_t Cout, int32_t H,
+                                    int32_t W, void* stream);
 /* TransformerBlock.forward, model/Restromer.py:163-167, on a packed tensor;      */
 /* y may alias x.  C % 8 == 0, C / heads a multiple of 16 (<= 192), C and hidden  */
 /* at most 480, W even.  Returns 0 bytes / RST_ERR_INVALID for unsupported shapes. */

@@ -96,6 +96,7 @@ SIGNATURES = {
     "rst_bf16_conv3x3_workspace_bytes": (c_size_t, [c_int32, c_int32]),
     "rst_bf16_conv3x3_supported": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32]),
     "rst_bf16_conv3x3_fwd": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, c_size_t, _P]),
+    "rst_bf16_conv3x3_fewout_fwd": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     "rst_bf16_block_workspace_bytes": (c_size_t, [_DESC]),
     "rst_bf16_block_prepared_bytes": (c_size_t, [_DESC]),
     "rst_bf16_block_prepare": (c_int32, [_DESC, _PAR, _P, _P]),

@@ -146,6 +146,29 @@ def conv3x3(p: Packed, weight: torch.Tensor, bias: Optional[torch.Tensor], mode:
     return Packed(out, Co)
 
 
+def conv3x3_fewout(p: Packed, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+                   lowres: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The network's last layer on a packed tensor (model/Restromer.py:381-383, 420-431): nn.Conv2d(Cin, Cout <= 4, 3,
+    padding=1) with fp32 weights and sums and an fp32 NCHW result, plus `residual` (fp32, the result's shape) or the
+    bilinear x2 of `lowres` (fp32, half the size) -- rst_bf16_conv3x3_fewout_fwd."""
+    lib = _lib.load()
+    B, Cin, H, W = p.shape
+    w, b = _f32(weight, "conv3x3 weight"), _f32(bias, "conv3x3 bias")
+    Cout = w.shape[0]
+    if tuple(w.shape) != (Cout, Cin, 3, 3) or Cout > 4:
+        raise RuntimeError(f"conv3x3_fewout: weight {tuple(w.shape)} does not fit {Cin} input channels / at most 4 outputs")
+    res = _f32(residual, "conv3x3 residual")
+    low = _f32(lowres, "conv3x3 low-resolution residual")
+    if res is not None and tuple(res.shape) != (B, Cout, H, W):
+        raise RuntimeError(f"conv3x3_fewout: residual {tuple(res.shape)} != {(B, Cout, H, W)}")
+    if low is not None and tuple(low.shape) != (B, Cout, H // 2, W // 2):
+        raise RuntimeError(f"conv3x3_fewout: low-resolution tensor {tuple(low.shape)} != {(B, Cout, H // 2, W // 2)}")
+    y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=p.data.device)
+    check(lib.rst_bf16_conv3x3_fewout_fwd(_ptr(p.data), _ptr(w), _ptr(b), _ptr(res), _ptr(low), _ptr(y), B, Cin, Cout, H, W, _stream()),
+          "rst_bf16_conv3x3_fewout_fwd")
+    return y
+
+
 class PreparedCache:
     """Prepared weights of one block (rst_bf16_block_prepare), rebuilt when a parameter tensor is replaced or
     modified in place (torch bumps ``_version`` on every in-place write, including optimizer steps, ``copy_`` and

@@ -211,6 +211,9 @@ struct PwDwPk {
     int B, H, W; int gate;
     int pb, ngroups, patches_per_block, rows;  // filled by the launcher
 };
+// dense 3x3 with at most 4 output channels: packed bf16 in, fp32 NCHW out (+ residual or + bilinear x2 of up_src)
+int fewout_pk_launch(const bf16_t* x, const float* w, const float* bias, const float* res, const float* up_src, float* y,
+                     int B, int Cin, int Cout, int H, int W, hipStream_t stream);
 bool pwdw_pk_supported(int Kb, int W, int H);
 int pwdw_pk_launch(PwDwPk g, hipStream_t stream);
 // Gram matrices q k^T and squared row norms over the pixels: `splits` slabs per (sample, head)

@@ -305,16 +305,16 @@ class Restormer(nn.Module):
         d2 = pk.conv1x1(pk.cat(up(d3, self.up3_2), e2), self.reduce_chan_level2.weight, self.reduce_chan_level2.bias)
         d2 = stage(d2, self.decoder_level2)
         d1 = stage(stage(pk.cat(up(d2, self.up2_1), e1), self.decoder_level1), self.refinement)
-        upx = pk.unpack(up(d1, self.output_upscale), torch.float32)
+        upk = up(d1, self.output_upscale)
         if self.dual_pixel_task:
-            out = self.output(upx + skip)
+            out = self.output(pk.unpack(upk, torch.float32) + skip)
+        elif self.output.weight.shape[0] <= 4 and not via_torch:
+            # last layer + bilinear x2 of the input in one kernel that reads the packed tensor: fp32 weights and sums, and
+            # the image never passes through a bf16 container on its way out
+            out = pk.conv3x3_fewout(upk, self.output.weight, self.output.bias, lowres=inp_img.float())
         else:
             base = F.interpolate(inp_img.float(), scale_factor=2, mode="bilinear", align_corners=False)
-            if self.output.weight.shape[0] <= 4:
-                bias = None if self.output.bias is None else self.output.bias.float()
-                out = ops.conv3x3_fewout(upx, self.output.weight.float(), bias, base)
-            else:
-                out = self.output(upx) + base
+            out = self.output(pk.unpack(upk, torch.float32)) + base
         return out.to(inp_img.dtype)
 
     def forward(self, inp_img):

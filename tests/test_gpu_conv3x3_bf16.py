@@ -59,3 +59,29 @@ def test_conv3x3_bf16_rejects_what_it_cannot_pack():
     x = bf16.pack(torch.randn(1, 48, 8, 64, device="cuda"))
     with pytest.raises(RuntimeError):
         bf16.conv3x3(x, torch.randn(20, 48, 3, 3, device="cuda"), None, 2)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,form", [(2, 48, 3, 12, 40, "lowres"), (1, 48, 3, 9, 26, "residual"), (1, 20, 4, 6, 8, "none"),
+                                                  (1, 48, 1, 5, 130, "residual"), (2, 96, 3, 16, 64, "lowres")])
+def test_conv3x3_fewout_bf16_vs_oracle(B, Cin, Cout, H, W, form):
+    """The last layer on a packed input (rst_bf16_conv3x3_fewout_fwd): fp32 weights and sums on the bf16-rounded input, fp32
+    result, plus a plain residual or the bilinear x2 of a low-resolution tensor -- against the oracle's conv3x3 (+ torch's
+    bilinear interpolation in fp64) on the same rounded input: only the fp32 summation order is left."""
+    from oracle import restormer_oracle as orc
+    from superresolution_amd import bf16
+    g = torch.Generator().manual_seed(B * 100 + Cin + Cout + H + W)
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16()
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g)
+    ref = orc.conv3x3(x.double(), w.double(), b.double())
+    res = low = None
+    if form == "residual":
+        res = torch.randn(B, Cout, H, W, generator=g)
+        ref = ref + res.double()
+    elif form == "lowres":
+        low = torch.rand(B, Cout, H // 2, W // 2, generator=g)
+        ref = ref + torch.nn.functional.interpolate(low.double(), scale_factor=2, mode="bilinear", align_corners=False)
+    y = bf16.conv3x3_fewout(bf16.pack(x.cuda()), w.cuda(), b.cuda(), None if res is None else res.cuda(), None if low is None else low.cuda())
+    assert y.dtype == torch.float32 and tuple(y.shape) == (B, Cout, H, W)
+    err = float((y.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 1e-5, err
