@@ -306,9 +306,7 @@ static int attention_tail(const rst_block_desc* d, const rst_block_params* p, At
     } else {
     RST_TRY(attention_gram(d, b, b.plan, row0, row1, b.gram_part, b.sqq_part, b.sqk_part, stream));
     if (b.plan.splits > 16) {
-        RST_TRY(reduce_slabs_launch(b.gram_part, b.gram_red, (int64_t)c * c, B * heads, b.plan.splits, 0, stream));
-        RST_TRY(reduce_slabs_launch(b.sqq_part, b.sqq_red, c, B * heads, b.plan.splits, 0, stream));
-        RST_TRY(reduce_slabs_launch(b.sqk_part, b.sqk_red, c, B * heads, b.plan.splits, 0, stream));
+        RST_TRY(reduce_slabs3_launch(b.gram_part, b.gram_red, (int64_t)c * c, b.sqq_part, b.sqq_red, c, b.sqk_part, b.sqk_red, c, B * heads, b.plan.splits, stream));
         RST_TRY(attn_softmax_launch(b.gram_red, b.sqq_red, b.sqk_red, p->temperature, b.attn, b.ghat, b.nq, b.nk,
                                     B, heads, c, 1, stream));
     } else {

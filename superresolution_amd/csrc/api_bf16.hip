@@ -205,9 +205,7 @@ static int pk_block_fwd(const rst_block_desc* d, const rst_block_params* p, cons
         RST_TRY(gram_pk_launch(g, stream));
     }
     if (b.splits > 16) {
-        RST_TRY(reduce_slabs_launch(b.gram_part, b.gram_red, (int64_t)c * c, B * heads, b.splits, 0, stream));
-        RST_TRY(reduce_slabs_launch(b.sqq_part, b.sqq_red, c, B * heads, b.splits, 0, stream));
-        RST_TRY(reduce_slabs_launch(b.sqk_part, b.sqk_red, c, B * heads, b.splits, 0, stream));
+        RST_TRY(reduce_slabs3_launch(b.gram_part, b.gram_red, (int64_t)c * c, b.sqq_part, b.sqq_red, c, b.sqk_part, b.sqk_red, c, B * heads, b.splits, stream));
         RST_TRY(attn_softmax_launch(b.gram_red, b.sqq_red, b.sqk_red, p->temperature, b.attn, nullptr, nullptr, nullptr,
                                     B, heads, c, 1, stream));
     } else {
@@ -415,9 +413,7 @@ static int pk_block_bwd(const rst_block_desc* d, const rst_block_params* p, cons
         g.splits = b.f.splits; g.chunk_px = b.f.chunk; g.partial = b.f.gram_part; g.sqq = b.f.sqq_part; g.sqk = b.f.sqk_part;
         RST_TRY(gram_pk_launch(g, stream));
         if (b.f.splits > 16) {
-            RST_TRY(reduce_slabs_launch(b.f.gram_part, b.f.gram_red, (int64_t)c * c, B * heads, b.f.splits, 0, stream));
-            RST_TRY(reduce_slabs_launch(b.f.sqq_part, b.f.sqq_red, c, B * heads, b.f.splits, 0, stream));
-            RST_TRY(reduce_slabs_launch(b.f.sqk_part, b.f.sqk_red, c, B * heads, b.f.splits, 0, stream));
+            RST_TRY(reduce_slabs3_launch(b.f.gram_part, b.f.gram_red, (int64_t)c * c, b.f.sqq_part, b.f.sqq_red, c, b.f.sqk_part, b.f.sqk_red, c, B * heads, b.f.splits, stream));
             RST_TRY(attn_softmax_launch(b.f.gram_red, b.f.sqq_red, b.f.sqk_red, p->temperature, b.f.attn, b.ghat, b.nq, b.nk,
                                         B, heads, c, 1, stream));
         } else {

@@ -538,6 +538,65 @@ int gemm_nt_launch(GemmNT g, const NtPlan& p, hipStream_t stream) {
     return RST_OK;
 }
 
+// The vector form for up to four tensors with the same (groups, slabs per group) in one launch: the three sums of an
+// attention (Gram matrix, squared norms of q and of k) are reduced together.  Same per-element order as above.
+struct ReduceJobs { const float* partial[4]; float* out[4]; int64_t elems[4]; int first_block[5]; };
+__global__ void __launch_bounds__(256)
+reduce_slabs_multi_kernel(const ReduceJobs jobs, int slabs_per_group) {
+    __shared__ f32x4 red[8][32];
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) j += (int)blockIdx.x >= jobs.first_block[k] ? 1 : 0;
+    const float* partial = jobs.partial[0]; float* out = jobs.out[0]; int64_t elems = jobs.elems[0]; int fb = jobs.first_block[0];
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (j == k) { partial = jobs.partial[k]; out = jobs.out[k]; elems = jobs.elems[k]; fb = jobs.first_block[k]; }
+    const int col = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int64_t e = ((int64_t)(blockIdx.x - fb) * 32 + col) * 4;
+    const int64_t grp = blockIdx.y;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (e < elems) {
+        const float* p = partial + grp * slabs_per_group * elems + e;
+        int i = sl;
+        for (; i + 24 < slabs_per_group; i += 32) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p + (int64_t)i * elems);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(p + (int64_t)(i + 8) * elems);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(p + (int64_t)(i + 16) * elems);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(p + (int64_t)(i + 24) * elems);
+            s += a; s += b; s += c; s += d;
+        }
+        for (; i < slabs_per_group; i += 8) s += *reinterpret_cast<const f32x4*>(p + (int64_t)i * elems);
+    }
+    red[sl][col] = s;
+    __syncthreads();
+    if (sl == 0 && e < elems) {
+        f32x4 t = red[0][col];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k][col];
+        *reinterpret_cast<f32x4*>(out + grp * elems + e) = t;
+    }
+}
+
+int reduce_slabs3_launch(const float* p0, float* o0, int64_t e0, const float* p1, float* o1, int64_t e1, const float* p2, float* o2,
+                         int64_t e2, int groups, int slabs_per_group, hipStream_t stream) {
+    const bool vec = e0 % 4 == 0 && e1 % 4 == 0 && e2 % 4 == 0 && aligned16(p0) && aligned16(p1) && aligned16(p2) && aligned16(o0) &&
+                     aligned16(o1) && aligned16(o2);
+    if (!vec) {
+        RST_TRY(reduce_slabs_launch(p0, o0, e0, groups, slabs_per_group, 0, stream));
+        RST_TRY(reduce_slabs_launch(p1, o1, e1, groups, slabs_per_group, 0, stream));
+        return reduce_slabs_launch(p2, o2, e2, groups, slabs_per_group, 0, stream);
+    }
+    ReduceJobs jobs{};
+    const float* ps[3] = {p0, p1, p2}; float* os[3] = {o0, o1, o2}; const int64_t es[3] = {e0, e1, e2};
+    int nb = 0;
+    for (int k = 0; k < 3; ++k) { jobs.partial[k] = ps[k]; jobs.out[k] = os[k]; jobs.elems[k] = es[k]; jobs.first_block[k] = nb; nb += (int)cdiv(es[k], 128); }
+    jobs.partial[3] = p2; jobs.out[3] = o2; jobs.elems[3] = 0; jobs.first_block[3] = nb; jobs.first_block[4] = nb;
+    ProfScope prof(stream, "reduce_slabs", (double)(e0 + e1 + e2) * groups * slabs_per_group, 4.0 * (e0 + e1 + e2) * groups * (slabs_per_group + 1.0));
+    hipLaunchKernelGGL(reduce_slabs_multi_kernel, dim3((unsigned)nb, (unsigned)groups), dim3(256), 0, stream, jobs, slabs_per_group);
+    RST_LAUNCH_CHECK();
+    return RST_OK;
+}
+
 int reduce_slabs_launch(const float* partial, float* out, int64_t elems, int groups, int slabs_per_group,
                         int accumulate, hipStream_t stream) {
     dim3 gd((unsigned)cdiv(elems, 256), (unsigned)groups), blk(256);

@@ -106,6 +106,9 @@ bool gram_f16s_supported(const GemmNT& g);
 int gram_f16s_launch(const GemmNT& g, hipStream_t stream);
 int reduce_slabs_launch(const float* partial, float* out, int64_t elems, int groups, int slabs_per_group,
                         int accumulate, hipStream_t stream);
+// three tensors with the same (groups, slabs per group) in one launch (out = sum, no accumulation)
+int reduce_slabs3_launch(const float* p0, float* o0, int64_t e0, const float* p1, float* o1, int64_t e1, const float* p2, float* o2,
+                         int64_t e2, int groups, int slabs_per_group, hipStream_t stream);
 
 // ---- dwconv.hip ----
 struct DwArgs {
