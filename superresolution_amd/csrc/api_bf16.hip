@@ -1,6 +1,8 @@
 // C ABI of the bf16 storage path (inference): channel-packed bf16 activations, fp32 parameters and sums.
 // Launch sequences only; the kernels are in bf16_pk.hip and attn_small.hip.
 #include "kernels.hpp"
+#include <map>
+#include <mutex>
 
 namespace rst {
 
@@ -301,7 +303,8 @@ struct PkBwdBufs {
     PkWeight wmfT;
     float *dw_qkv_flip, *dw_ffn_flip;
     float *part, *red, *dw_part, *dw_red;          // red: [M][K] sums, then M row sums
-    size_t part_floats, dw_floats;
+    float* part_p;                                  // slabs of P = dx1 v^T (its own: that product runs beside the others)
+    size_t part_floats, part_p_floats, dw_floats;
 };
 
 WgradPk pk_wgrad_shape(int Ab, int Bb, int B, int64_t N, bool with_rowsum) {
@@ -344,6 +347,8 @@ void pk_bwd_carve(const rst_block_desc* d, Carve& cv, PkBwdBufs& b) {
         b.part_floats = b.part_floats > wgrad_pk_partial_floats(g) ? b.part_floats : wgrad_pk_partial_floats(g);
     }
     b.part = cv.floats(b.part_floats);
+    b.part_p_floats = wgrad_pk_partial_floats(pk_wgrad_shape(C / 8, C / 8, B, N, false));
+    b.part_p = cv.floats(b.part_p_floats);
     const int wmax = 3 * C > 2 * Hp ? 3 * C : 2 * Hp;
     b.red = cv.floats((size_t)wmax * (C > Hp ? C : Hp) + wmax);
     const size_t dwa = dw_wgrad_pk_partial_floats(B, 3 * C / 8, d->H, d->W), dwb = dw_wgrad_pk_partial_floats(B, 2 * Hp / 8, d->H, d->W);
@@ -360,14 +365,44 @@ size_t pk_block_bwd_ws_bytes(const rst_block_desc* d) {
 // out = sum over (samples and) splits of the product over the pixels, [Ab*8][Bb*8] (+ the Ab*8 row sums of A behind
 // it when asked); `per_sample`: one such record per sample
 int pk_wgrad(const bf16_t* a, int64_t a_bs, int Ab, const bf16_t* bm, int64_t b_bs, int Bb, int B, int64_t N, bool per_sample,
-             bool with_rowsum, float* out, PkBwdBufs& b, hipStream_t stream) {
+             bool with_rowsum, float* out, float* part, size_t part_floats, hipStream_t stream) {
     WgradPk g = pk_wgrad_shape(Ab, Bb, B, N, with_rowsum);
     g.A = a; g.a_bs = a_bs; g.Bm = bm; g.b_bs = b_bs;
-    g.partial = b.part;
-    RST_REQUIRE(wgrad_pk_partial_floats(g) <= b.part_floats, "bf16 block backward: weight-gradient scratch too small");
+    g.partial = part;
+    RST_REQUIRE(wgrad_pk_partial_floats(g) <= part_floats, "bf16 block backward: weight-gradient scratch too small");
     RST_TRY(wgrad_pk_launch(g, stream));
     const int64_t rec = (int64_t)Ab * 8 * Bb * 8 + (with_rowsum ? Ab * 8 : 0);
-    return reduce_slabs_launch(b.part, out, rec, per_sample ? B : 1, per_sample ? g.splits : B * g.splits, 0, stream);
+    return reduce_slabs_launch(part, out, rec, per_sample ? B : 1, per_sample ? g.splits : B * g.splits, 0, stream);
+}
+
+// The backward pass of a block is two kinds of work: the chain of data gradients (each kernel waits for the one before
+// it) and the parameter gradients (products over the pixels, slab sums, small rearrangements), which only READ what
+// the chain leaves behind.  At training sizes most of these kernels fill a fraction of the chip, so the parameter
+// gradients run on a second stream of the library's own, one per device: it waits for an event the caller's stream
+// records when an operand is ready, and the caller's stream waits for it once, before the call returns.  Calls that
+// overlap on one device share that stream (ordering stays correct, the overlap is lost).  RST_BWD_STREAMS=0 keeps
+// everything on the caller's stream.
+struct SideStream {
+    hipStream_t s = nullptr;
+    hipEvent_t fork[8] = {};
+    hipEvent_t join = nullptr;
+};
+int side_stream_for_current_device(SideStream** out) {
+    static std::mutex mu;
+    static std::map<int, SideStream> per_device;
+    int dev = 0;
+    RST_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = per_device.find(dev);
+    if (it == per_device.end()) {
+        SideStream sd;
+        RST_HIP(hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking));
+        for (auto& e : sd.fork) RST_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        RST_HIP(hipEventCreateWithFlags(&sd.join, hipEventDisableTiming));
+        it = per_device.emplace(dev, sd).first;
+    }
+    *out = &it->second;
+    return RST_OK;
 }
 
 }  // namespace
@@ -397,6 +432,21 @@ static int pk_block_bwd(const rst_block_desc* d, const rst_block_params* p, cons
         RST_TRY(pk_block_prepare(d, p, b.f, stream));
     }
 
+    static const bool two_streams = !(getenv("RST_BWD_STREAMS") != nullptr && getenv("RST_BWD_STREAMS")[0] == '0');
+    SideStream* sd = nullptr;
+    if (two_streams) RST_TRY(side_stream_for_current_device(&sd));
+    const hipStream_t side = sd ? sd->s : stream;
+    int nfork = 0;
+    // what the caller's stream has queued so far is complete before anything queued on the side stream from here on
+    auto fork = [&]() -> int {
+        if (sd == nullptr) return RST_OK;
+        RST_REQUIRE(nfork < 8, "bf16 block backward: out of fork events");
+        RST_HIP(hipEventRecord(sd->fork[nfork], stream));
+        RST_HIP(hipStreamWaitEvent(side, sd->fork[nfork], 0));
+        ++nfork;
+        return RST_OK;
+    };
+    auto body = [&]() -> int {
     // ---------------- forward again, everything kept ----------------
     {
         GemmPk g = pk_gemm_args(b.f.wqkv, x, cn, b.t, 3 * cn, B, N);
@@ -463,42 +513,48 @@ static int pk_block_bwd(const rst_block_desc* d, const rst_block_params* p, cons
     RST_TRY(pk_prep_dw_launch(p->ffn_dw_weight, nullptr, 2 * Hd, Hd, -1, 2 * Hp / 8, b.dw_ffn_flip, stream, 1));
 
     // ---------------- GDFN: y = x1 + Wout (gelu(d1) d2), d = dw(Win LN2(x1)) ----------------
-    RST_TRY(pk_wgrad(dy, cn, C / 8, b.g, hn, Hp / 8, B, N, false, cb, b.red, b, stream));
-    RST_TRY(crop2d_launch(b.red, Hp, gr->pout_weight, C, Hd, stream));
-    if (cb) RST_HIP(hipMemcpyAsync(gr->pout_bias, b.red + (size_t)C * Hp, sizeof(float) * C, hipMemcpyDeviceToDevice, stream));
+    RST_TRY(fork());                                 // g (and x1, for the statistics below) are there
+    RST_TRY(pk_wgrad(dy, cn, C / 8, b.g, hn, Hp / 8, B, N, false, cb, b.red, b.part, b.part_floats, side));
+    RST_TRY(crop2d_launch(b.red, Hp, gr->pout_weight, C, Hd, side));
+    if (cb) RST_HIP(hipMemcpyAsync(gr->pout_bias, b.red + (size_t)C * Hp, sizeof(float) * C, hipMemcpyDeviceToDevice, side));
+    RST_TRY(ln_fwd_pk_launch(b.x1, b.xh, B, C / 8, N, wb, side));
     RST_TRY(pk_sliced_gemm(b.wpoutT, dy, cn, b.dg, hn, B, N, 0, stream));
     RST_TRY(gate_bwd_pk_launch(b.dg, b.d, b.dd, B, Hp / 8, N, stream));
+    RST_TRY(fork());                                 // dd
     {
         DwWgradPk a{};
         a.dy = b.dd; a.dy_bs = 2 * hn; a.x = b.u; a.x_bs = 2 * hn; a.B = B; a.Cb = 2 * Hp / 8; a.H = d->H; a.W = d->W;
         a.partial = b.dw_part;
-        RST_TRY(dw_wgrad_pk_launch(a, b.dw_red, stream));
-        RST_TRY(dw_grad_unpack_launch(b.dw_red, gr->ffn_dw_weight, cb ? gr->ffn_dw_bias : nullptr, 2 * Hd, Hd, -1, 2 * Hp / 8, stream));
+        RST_TRY(dw_wgrad_pk_launch(a, b.dw_red, side));
+        RST_TRY(dw_grad_unpack_launch(b.dw_red, gr->ffn_dw_weight, cb ? gr->ffn_dw_bias : nullptr, 2 * Hd, Hd, -1, 2 * Hp / 8, side));
         DwPk w{};
         w.x = b.dd; w.x_bs = 2 * hn; w.wp = b.dw_ffn_flip; w.y = b.du; w.y_bs = 2 * hn;
         w.B = B; w.Cb = 2 * Hp / 8; w.H = d->H; w.W = d->W; w.gate = 0;
         RST_TRY(dw_pk_launch(w, stream));
     }
-    RST_TRY(ln_fwd_pk_launch(b.x1, b.xh, B, C / 8, N, wb, stream));
-    RST_TRY(pk_wgrad(b.du, 2 * hn, 2 * Hp / 8, b.xh, cn, C / 8, B, N, false, true, b.red, b, stream));
+    RST_TRY(fork());                                 // du
+    RST_TRY(pk_wgrad(b.du, 2 * hn, 2 * Hp / 8, b.xh, cn, C / 8, B, N, false, true, b.red, b.part, b.part_floats, side));
     RST_TRY(lnlin_grads_launch(b.red, b.red + (size_t)2 * Hp * C, p->pin_weight, p->norm2_weight, wb ? p->norm2_bias : nullptr, gr->pin_weight,
-                               cb ? gr->pin_bias : nullptr, gr->norm2_weight, wb ? gr->norm2_bias : nullptr, 2 * Hd, C, Hd, -1, stream));
+                               cb ? gr->pin_bias : nullptr, gr->norm2_weight, wb ? gr->norm2_bias : nullptr, 2 * Hd, C, Hd, -1, side));
     RST_TRY(pk_sliced_gemm(b.wpinT, b.du, 2 * hn, b.dn, cn, B, N, 0, stream));
     RST_TRY(ln_bwd_pk_launch(b.dn, b.x1, p->norm2_weight, dy, b.dx1, B, C / 8, N, wb, stream));
 
     // ---------------- MDTA: x1 = x + M_b v, M_b = Wo blockdiag(softmax) ----------------
     const bf16_t* q = b.qkv; const bf16_t* k = b.qkv + cn; const bf16_t* v = b.qkv + 2 * cn;
-    RST_TRY(pk_wgrad(b.dx1, cn, C / 8, v, 3 * cn, C / 8, B, N, true, false, b.P, b, stream));
     if (cb) {
         // the projection's bias gradient: the sums of dx1's rows over everything (the product with its own rows is a
         // by-product nobody reads)
-        RST_TRY(pk_wgrad(b.dx1, cn, C / 8, b.dx1, cn, 1, B, N, false, true, b.red, b, stream));
-        RST_HIP(hipMemcpyAsync(gr->proj_bias, b.red + (size_t)C * 8, sizeof(float) * C, hipMemcpyDeviceToDevice, stream));
+        RST_TRY(fork());                             // dx1
+        RST_TRY(pk_wgrad(b.dx1, cn, C / 8, b.dx1, cn, 1, B, N, false, true, b.red, b.part, b.part_floats, side));
+        RST_HIP(hipMemcpyAsync(gr->proj_bias, b.red + (size_t)C * 8, sizeof(float) * C, hipMemcpyDeviceToDevice, side));
     }
+    RST_TRY(pk_wgrad(b.dx1, cn, C / 8, v, 3 * cn, C / 8, B, N, true, false, b.P, b.part_p, b.part_p_floats, stream));
     RST_TRY(attn_bwd_small_launch(b.P, p->proj_weight, b.f.attn, b.ghat, b.nq, b.nk, p->temperature, b.Eq, b.Dq, b.Dk,
                                   b.dGG, b.dtemp_row, b.dtemp_b, b.dwo_b, B, C, heads, c, stream));
-    RST_TRY(reduce_slabs_launch(b.dwo_b, gr->proj_weight, (int64_t)C * C, 1, B, 0, stream));
-    RST_TRY(reduce_slabs_launch(b.dtemp_b, gr->temperature, heads, 1, B, 0, stream));
+    RST_TRY(fork());                                 // the per-sample sums of the attention's parameter gradients
+    RST_TRY(reduce_slabs_launch(b.dwo_b, gr->proj_weight, (int64_t)C * C, 1, B, 0, side));
+    RST_TRY(reduce_slabs_launch(b.dtemp_b, gr->temperature, heads, 1, B, 0, side));
+    RST_TRY(ln_fwd_pk_launch(x, b.xh, B, C / 8, N, wb, side));      // (the product that read x1's statistics is queued before it)
     RST_TRY(attn_bwd_mats_launch(b.Eq, b.Dq, b.Dk, b.mats, B, C, c, stream));
     for (int i = 0; i < b.wmat.nslices; ++i)
         RST_TRY(pk_prep_at_launch(b.mats, (int64_t)4 * C * C, 2 * C, 0, 2 * C, NOSEG, NOSEG, 2 * C, NOSEG, NOSEG, b.wmat.kpos0[i],
@@ -518,23 +574,32 @@ static int pk_block_bwd(const rst_block_desc* d, const rst_block_params* p, cons
         g.a_bs = (int64_t)b.wmfT.frag_elems() / 8;
         RST_TRY(gemm_pk_launch(g, stream));
     }
+    RST_TRY(fork());                                 // dqkv
     {
         DwWgradPk a{};
         a.dy = b.dqkv; a.dy_bs = 3 * cn; a.x = b.t; a.x_bs = 3 * cn; a.B = B; a.Cb = 3 * C / 8; a.H = d->H; a.W = d->W;
         a.partial = b.dw_part;
-        RST_TRY(dw_wgrad_pk_launch(a, b.dw_red, stream));
-        RST_TRY(dw_grad_unpack_launch(b.dw_red, gr->qkv_dw_weight, cb ? gr->qkv_dw_bias : nullptr, 3 * C, NOSEG, NOSEG, 3 * C / 8, stream));
+        RST_TRY(dw_wgrad_pk_launch(a, b.dw_red, side));
+        RST_TRY(dw_grad_unpack_launch(b.dw_red, gr->qkv_dw_weight, cb ? gr->qkv_dw_bias : nullptr, 3 * C, NOSEG, NOSEG, 3 * C / 8, side));
         DwPk w{};
         w.x = b.dqkv; w.x_bs = 3 * cn; w.wp = b.dw_qkv_flip; w.y = b.dt; w.y_bs = 3 * cn;
         w.B = B; w.Cb = 3 * C / 8; w.H = d->H; w.W = d->W; w.gate = 0;
         RST_TRY(dw_pk_launch(w, stream));
     }
-    RST_TRY(ln_fwd_pk_launch(x, b.xh, B, C / 8, N, wb, stream));
-    RST_TRY(pk_wgrad(b.dt, 3 * cn, 3 * C / 8, b.xh, cn, C / 8, B, N, false, true, b.red, b, stream));
+    RST_TRY(fork());                                 // dt
+    RST_TRY(pk_wgrad(b.dt, 3 * cn, 3 * C / 8, b.xh, cn, C / 8, B, N, false, true, b.red, b.part, b.part_floats, side));
     RST_TRY(lnlin_grads_launch(b.red, b.red + (size_t)3 * C * C, p->qkv_weight, p->norm1_weight, wb ? p->norm1_bias : nullptr, gr->qkv_weight,
-                               cb ? gr->qkv_bias : nullptr, gr->norm1_weight, wb ? gr->norm1_bias : nullptr, 3 * C, C, NOSEG, NOSEG, stream));
+                               cb ? gr->qkv_bias : nullptr, gr->norm1_weight, wb ? gr->norm1_bias : nullptr, 3 * C, C, NOSEG, NOSEG, side));
     RST_TRY(pk_sliced_gemm(b.wqkvT, b.dt, 3 * cn, b.dn, cn, B, N, 0, stream));
     return ln_bwd_pk_launch(b.dn, x, p->norm1_weight, b.dx1, dx, B, C / 8, N, wb, stream);
+    };
+    const int rc = body();
+    if (sd != nullptr && nfork > 0) {
+        // the caller's stream goes on only after the side stream has drained -- also when the body gave up half-way
+        RST_HIP(hipEventRecord(sd->join, side));
+        RST_HIP(hipStreamWaitEvent(stream, sd->join, 0));
+    }
+    return rc;
 }
 
 }  // namespace rst

@@ -235,7 +235,9 @@ int wgrad_pk_launch(const WgradPk& g, hipStream_t stream) {
 }
 
 // ---- depthwise 3x3: tap sums --------------------------------------------------------------------------------
-// partial[(b, row chunk)][cb][80]: [tap][8 channels] sums of dy[p] x[p + tap] over the chunk's pixels, then the 8 sums of dy
+// partial[(b, row chunk)][cb][80]: [tap][8 channels] sums of dy[p] x[p + tap] over the chunk's pixels, then the 8 sums of dy.
+// A thread takes runs of 8 pixels of a row: the 10 chunks of x a row of taps needs are read once for the run
+// (38 16-byte loads per 8 pixels instead of 80), out-of-image chunks as zeros through the buffer descriptor's range.
 __global__ void __launch_bounds__(256)
 dw_wgrad_pk_kernel(const DwWgradPk a) {
     __shared__ float red[4][80];
@@ -244,30 +246,53 @@ dw_wgrad_pk_kernel(const DwWgradPk a) {
     const int H = a.H, W = a.W;
     const int r0 = blockIdx.x * a.rows;
     const int r1 = r0 + a.rows < H ? r0 + a.rows : H;
-    const u32x4* X = reinterpret_cast<const u32x4*>(a.x + (int64_t)b * a.x_bs) + (int64_t)cb * H * W;
-    const u32x4* D = reinterpret_cast<const u32x4*>(a.dy + (int64_t)b * a.dy_bs) + (int64_t)cb * H * W;
+    const int64_t plane = (int64_t)H * W;
+    const __amdgpu_buffer_rsrc_t X = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(a.x + (int64_t)b * a.x_bs + (int64_t)cb * plane * 8), 0, (int)(plane * 16), 0x00020000);
+    const __amdgpu_buffer_rsrc_t D = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(a.dy + (int64_t)b * a.dy_bs + (int64_t)cb * plane * 8), 0, (int)(plane * 16), 0x00020000);
+    constexpr int OOR = (int)0x80000000;             // an offset no buffer reaches: the load returns zeros
     float acc[80];
 #pragma unroll
     for (int k = 0; k < 80; ++k) acc[k] = 0.f;
-    const int npx = (r1 - r0) * W;
-    for (int idx = threadIdx.x; idx < npx; idx += 256) {
-        const int y = r0 + idx / W, x = idx % W;
-        float d[8];
-        unpack8(D[(int64_t)y * W + x], d);
+    const int runs_w = (W + 7) >> 3;
+    const int nruns = (r1 - r0) * runs_w;
+    for (int idx = threadIdx.x; idx < nruns; idx += 256) {
+        const int y = r0 + idx / runs_w, x0 = (idx % runs_w) * 8;
+        u32x4 dq[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[72 + j] += d[j];
+        for (int i = 0; i < 8; ++i)
+            dq[i] = __builtin_amdgcn_raw_buffer_load_b128(D, x0 + i < W ? (y * W + x0 + i) * 16 : OOR, 0, 0);
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int i = 0; i < 8; ++i) {
+            float d[8];
+            unpack8(dq[i], d);
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int yy = y + ky - 1, xx = x + kx - 1;
-                if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            for (int j = 0; j < 8; ++j) acc[72 + j] += d[j];
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = y + ky - 1;
+            const bool row_in = yy >= 0 && yy < H;
+            u32x4 xq[10];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                const int xx = x0 + i - 1;
+                xq[i] = __builtin_amdgcn_raw_buffer_load_b128(X, row_in && xx >= 0 && xx < W ? (yy * W + xx) * 16 : OOR, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float d[8];
+                unpack8(dq[i], d);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
                     float v[8];
-                    unpack8(X[(int64_t)yy * W + xx], v);
+                    unpack8(xq[i + kx], v);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) acc[(ky * 3 + kx) * 8 + j] = fmaf(d[j], v[j], acc[(ky * 3 + kx) * 8 + j]);
                 }
             }
+        }
     }
     // sums over the block: 40 values at a time through an LDS image [wave][value][lane] (each lane then adds one row)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -305,6 +330,7 @@ size_t dw_wgrad_pk_partial_floats(int B, int Cb, int H, int W) {
 int dw_wgrad_pk_launch(DwWgradPk a, float* red, hipStream_t stream) {
     RST_REQUIRE(a.dy && a.x && a.partial && red && a.B > 0 && a.Cb > 0 && a.H > 0 && a.W > 0, "bf16 depthwise gradient: bad operand");
     RST_REQUIRE(a.B <= 65535 && a.Cb <= 65535, "bf16 depthwise gradient: grid too large");
+    RST_REQUIRE((int64_t)a.H * a.W < (1ll << 27), "bf16 depthwise gradient: plane beyond a buffer descriptor's 2 GiB");
     a.rows = dw_wgrad_pk_rows(a.B, a.Cb, a.H, a.W);
     const int nchunks = (int)cdiv(a.H, a.rows);
     {
@@ -556,13 +582,29 @@ lnlin_dgamma_kernel(const float* __restrict__ G, const float* __restrict__ S, co
     const int cl = threadIdx.x & 15, ph = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     float a = 0.f, bsum = 0.f;
-    if (c < C)
-        for (int m = ph; m < M; m += 16) {
+    if (c < C) {
+        // four rows in flight per thread: the loop is a chain of dependent cache misses otherwise
+        float a4[4] = {0.f, 0.f, 0.f, 0.f}, b4[4] = {0.f, 0.f, 0.f, 0.f};
+        int m = ph;
+        for (; m + 48 < M; m += 64) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int mm = m + 16 * u;
+                const int pos = dst_position(mm, seg, seg_pad);
+                const float w = W[(int64_t)mm * C + c];
+                a4[u] = fmaf(w, G[(int64_t)pos * C + c], a4[u]);
+                b4[u] = fmaf(w, S[pos], b4[u]);
+            }
+        }
+        for (; m < M; m += 16) {
             const int pos = dst_position(m, seg, seg_pad);
             const float w = W[(int64_t)m * C + c];
-            a = fmaf(w, G[(int64_t)pos * C + c], a);
-            bsum = fmaf(w, S[pos], bsum);
+            a4[0] = fmaf(w, G[(int64_t)pos * C + c], a4[0]);
+            b4[0] = fmaf(w, S[pos], b4[0]);
         }
+        a = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+        bsum = (b4[0] + b4[1]) + (b4[2] + b4[3]);
+    }
     red[0][ph][cl] = a; red[1][ph][cl] = bsum;
     __syncthreads();
     if (ph == 0 && c < C) {
