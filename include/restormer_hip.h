@@ -388,6 +388,22 @@ size_t rst_bf16_block_bwd_workspace_bytes(const rst_block_desc* desc);
 int rst_bf16_block_bwd(const rst_block_desc* desc, const rst_block_params* params, const void* prepared,
                        const void* x_packed, const void* dy_packed, void* dx_packed,
                        rst_block_grads* grads, void* workspace, size_t workspace_bytes, void* stream);
+/* The same pair for a training step that can spare a little memory per block     */
+/* (what autograd keeps of model/Restromer.py:141-146 -- attn before and after      */
+/* the softmax -- plus the norms of q and k and the product with project_out):      */
+/* rst_bf16_block_fwd_keep also writes these small fp32 matrices into `kept`, a     */
+/* caller-owned device buffer of rst_bf16_block_kept_bytes (16-byte aligned;         */
+/* B*C*(C + 2*C/heads + 2) floats), and rst_bf16_block_bwd_kept reads them instead   */
+/* of forming them again from q and k: the gradients are those of the attention the */
+/* forward pass applied.  Everything else as for rst_bf16_block_fwd / _bwd.          */
+size_t rst_bf16_block_kept_bytes(const rst_block_desc* desc);
+int rst_bf16_block_fwd_keep(const rst_block_desc* desc, const rst_block_params* params,
+                            const void* prepared, const void* x_packed, void* y_packed, void* kept,
+                            void* workspace, size_t workspace_bytes, void* stream);
+int rst_bf16_block_bwd_kept(const rst_block_desc* desc, const rst_block_params* params, const void* prepared,
+                            const void* x_packed, const void* dy_packed, void* dx_packed,
+                            rst_block_grads* grads, const void* kept, void* workspace, size_t workspace_bytes,
+                            void* stream);
 
 /* ------------------------------------------------------------------------- */
 /* Dataset item on the GPU -- replaces LazyRAWDataset.__getitem__,             */

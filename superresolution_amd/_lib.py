@@ -103,6 +103,9 @@ SIGNATURES = {
     "rst_bf16_block_fwd": (c_int32, [_DESC, _PAR, _P, _P, _P, _P, c_size_t, _P]),
     "rst_bf16_block_bwd_workspace_bytes": (c_size_t, [_DESC]),
     "rst_bf16_block_bwd": (c_int32, [_DESC, _PAR, _P, _P, _P, _P, _GR, _P, c_size_t, _P]),
+    "rst_bf16_block_kept_bytes": (c_size_t, [_DESC]),
+    "rst_bf16_block_fwd_keep": (c_int32, [_DESC, _PAR, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "rst_bf16_block_bwd_kept": (c_int32, [_DESC, _PAR, _P, _P, _P, _P, _GR, _P, _P, c_size_t, _P]),
     "rst_raw_prepare": (c_int32, [_P, c_int32, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
     "rst_profile_begin": (c_int32, []),
     "rst_profile_end": (c_int32, [c_char_p, c_size_t]),

@@ -227,9 +227,11 @@ def cat(a: Packed, b: Packed) -> Packed:
 class _StageFn(torch.autograd.Function):
     """A run of TransformerBlocks (one `nn.Sequential` of the network) on bf16 activations, differentiable.
 
-    Forward: the packed bf16 inference kernels (`rst_bf16_block_fwd`, fused); nothing is kept but each block's INPUT
+    Forward: the packed bf16 inference kernels (`rst_bf16_block_fwd_keep`, fused); what is kept is each block's INPUT
     in packed bf16 -- 2 bytes per element and block instead of the ~26 fp32 values per element that the fp32
-    training forward keeps.  Backward, block by block in reverse: `rst_bf16_block_bwd` evaluates the block again on
+    training forward keeps -- and its attention's small matrices (softmax, normalised Gram matrix, norms, the product
+    with project_out: B*C*(C + 2c + 2) floats, nothing that grows with the image; ``RST_BF16_KEEP_ATTN=0``: not even
+    those).  Backward, block by block in reverse: `rst_bf16_block_bwd_kept` evaluates the block again on
     the kept input (activation recomputation, bf16 storage) and returns the packed bf16 gradient of the input and
     the fp32 gradients of the parameters.  So: bf16 activations and activation gradients, fp32 sums, fp32 parameters
     and parameter gradients.  ``RST_BF16_BWD=fp32`` switches the backward to the fp32 kernels on the unpacked input
@@ -241,18 +243,23 @@ class _StageFn(torch.autograd.Function):
         lib = _lib.load()
         if not x.is_cuda or x.dtype != torch.bfloat16:
             raise RuntimeError("bf16 stage: expected a bf16 tensor on a ROCm GPU")
+        import os
         p = pack(x)
-        kept = []
+        kept, attn = [], []
+        keep_attn = os.environ.get("RST_BF16_KEEP_ATTN", "1") != "0"
         n = len(PARAM_FIELDS)
         for i, (heads, hidden) in enumerate(metas):
             params = dict(zip(PARAM_FIELDS, flat[i * n:(i + 1) * n]))
             kept.append(p.data)
             out = Packed(torch.empty_like(p.data), p.C)
-            _block_into(lib, p, out, heads, hidden, params, caches[i])
+            a = _block_into(lib, p, out, heads, hidden, params, caches[i], keep_attn)
+            if keep_attn:
+                attn.append(a)
             p = out
         ctx.metas, ctx.shape, ctx.caches = metas, tuple(x.shape), caches
         ctx.present = [t is not None for t in flat]
-        ctx.save_for_backward(*kept, *[t for t in flat if t is not None])
+        ctx.keep_attn = keep_attn
+        ctx.save_for_backward(*kept, *attn, *[t for t in flat if t is not None])
         return unpack(p, torch.bfloat16)
 
     @staticmethod
@@ -260,7 +267,8 @@ class _StageFn(torch.autograd.Function):
         import os
         lib = _lib.load()
         nb = len(ctx.metas)
-        kept, rest = ctx.saved_tensors[:nb], iter(ctx.saved_tensors[nb:])
+        na = nb if ctx.keep_attn else 0
+        kept, attn, rest = ctx.saved_tensors[:nb], ctx.saved_tensors[nb:nb + na], iter(ctx.saved_tensors[nb + na:])
         flat = [next(rest) if pr else None for pr in ctx.present]
         B, C, H, W = ctx.shape
         n = len(PARAM_FIELDS)
@@ -280,17 +288,19 @@ class _StageFn(torch.autograd.Function):
         for i in reversed(range(nb)):
             heads, hidden = ctx.metas[i]
             params = dict(zip(PARAM_FIELDS, flat[i * n:(i + 1) * n]))
-            g, pg = block_backward(Packed(kept[i], C), g, heads, hidden, params, ctx.caches[i])
+            g, pg = block_backward(Packed(kept[i], C), g, heads, hidden, params, ctx.caches[i], attn[i] if na else None)
             for j, name in enumerate(PARAM_FIELDS):
                 grads[i * n + j] = pg[name]
         return (unpack(g, torch.bfloat16), None, None) + tuple(grads)
 
 
 def block_backward(x: Packed, dy: Packed, heads: int, hidden: int, params: Dict[str, Optional[torch.Tensor]],
-                   cache: Optional[PreparedCache] = None):
+                   cache: Optional[PreparedCache] = None, kept_attn: Optional[torch.Tensor] = None):
     """Gradients of one TransformerBlock from its packed bf16 input and the packed gradient of its output
     (`rst_bf16_block_bwd`).  Returns (dx packed, {parameter name: fp32 gradient or None}).  With the block's `cache`
-    the weights prepared for the forward pass are used again (they are rebuilt if a parameter changed since)."""
+    the weights prepared for the forward pass are used again (they are rebuilt if a parameter changed since); with
+    `kept_attn` (what `block_forward_keep` returned for this input) the attention is not formed again
+    (`rst_bf16_block_bwd_kept`)."""
     lib = _lib.load()
     B, C, H, W = x.shape
     tensors = {n: _f32(None if params.get(n) is None else params[n].detach(), n) for n in PARAM_FIELDS}
@@ -306,12 +316,27 @@ def block_backward(x: Packed, dy: Packed, heads: int, hidden: int, params: Dict[
         prepared = cache.get(lib, desc, par, {n: params.get(n) for n in PARAM_FIELDS}, x.data.device)
     ws = workspace(nb, x.data.device)
     dx = Packed(torch.empty_like(x.data), x.C)
-    check(lib.rst_bf16_block_bwd(ctypes.byref(desc), ctypes.byref(par), _ptr(prepared), _ptr(x.data), _ptr(dy.data), _ptr(dx.data), ctypes.byref(gr),
-                                 _ptr(ws), ws.numel(), _stream()), "rst_bf16_block_bwd")
+    if kept_attn is not None:
+        if kept_attn.dtype != torch.uint8 or kept_attn.numel() < lib.rst_bf16_block_kept_bytes(ctypes.byref(desc)) or not kept_attn.is_cuda:
+            raise RuntimeError("bf16 block backward: kept attention buffer of the wrong size, type or device")
+        check(lib.rst_bf16_block_bwd_kept(ctypes.byref(desc), ctypes.byref(par), _ptr(prepared), _ptr(x.data), _ptr(dy.data), _ptr(dx.data),
+                                          ctypes.byref(gr), _ptr(kept_attn), _ptr(ws), ws.numel(), _stream()), "rst_bf16_block_bwd_kept")
+    else:
+        check(lib.rst_bf16_block_bwd(ctypes.byref(desc), ctypes.byref(par), _ptr(prepared), _ptr(x.data), _ptr(dy.data), _ptr(dx.data), ctypes.byref(gr),
+                                     _ptr(ws), ws.numel(), _stream()), "rst_bf16_block_bwd")
     return dx, grads
 
 
-def _block_into(lib, src: Packed, dst: Packed, heads, hidden, params, cache):
+def block_forward_keep(x: Packed, heads: int, hidden: int, params: Dict[str, Optional[torch.Tensor]],
+                       cache: Optional[PreparedCache] = None):
+    """TransformerBlock on a packed tensor for a training step: returns (y packed, kept attention) -- the second is
+    what `block_backward(..., kept_attn=)` wants (`rst_bf16_block_fwd_keep`)."""
+    out = Packed(torch.empty_like(x.data), x.C)
+    kept = _block_into(_lib.load(), x, out, heads, hidden, params, cache, True)
+    return out, kept
+
+
+def _block_into(lib, src: Packed, dst: Packed, heads, hidden, params, cache, keep_attn=False):
     B, C, H, W = src.shape
     tensors = {n: _f32(params.get(n), n) for n in PARAM_FIELDS}
     desc = make_desc(B, C, H, W, heads, hidden, tensors["norm1_bias"] is not None, tensors["qkv_bias"] is not None)
@@ -321,8 +346,14 @@ def _block_into(lib, src: Packed, dst: Packed, heads, hidden, params, cache):
     par = _fill(BlockParams(), tensors)
     prepared = cache.get(lib, desc, par, {n: params.get(n) for n in PARAM_FIELDS}, src.data.device) if cache is not None else None
     ws = workspace(nb, src.data.device)
+    if keep_attn:
+        kept = torch.empty(lib.rst_bf16_block_kept_bytes(ctypes.byref(desc)), dtype=torch.uint8, device=src.data.device)
+        check(lib.rst_bf16_block_fwd_keep(ctypes.byref(desc), ctypes.byref(par), _ptr(prepared), _ptr(src.data), _ptr(dst.data), _ptr(kept),
+                                          _ptr(ws), ws.numel(), _stream()), "rst_bf16_block_fwd_keep")
+        return kept
     check(lib.rst_bf16_block_fwd(ctypes.byref(desc), ctypes.byref(par), _ptr(prepared), _ptr(src.data), _ptr(dst.data), _ptr(ws),
                                  ws.numel(), _stream()), "rst_bf16_block_fwd")
+    return None
 
 
 def stage(x: torch.Tensor, blocks) -> torch.Tensor:

@@ -402,7 +402,8 @@ static int attention_bwd(const rst_block_desc* d, const rst_block_params* p, con
     }
     if (d->conv_bias) RST_TRY(rowsum_launch(dy, (int64_t)C * N, gr->proj_bias, B, C, N, b.rsws, b.rsws_bytes, stream));
     RST_TRY(attn_bwd_small_launch(b.P, p->proj_weight, s.attn, s.ghat, s.nq, s.nk, p->temperature, b.Eq, b.Dq, b.Dk,
-                                  b.dGG, b.dtemp_row, b.dtemp_b, b.dwo_b, B, C, heads, c, stream));
+                                  b.dGG, b.dtemp_row, b.dtemp_b, B, C, heads, c, stream));
+    RST_TRY(attn_bwd_wo_launch(b.P, s.attn, b.dwo_b, B, C, heads, c, stream));
     RST_TRY(reduce_slabs_launch(b.dwo_b, gr->proj_weight, (int64_t)C * C, 1, B, 0, stream));
     RST_TRY(reduce_slabs_launch(b.dtemp_b, gr->temperature, heads, 1, B, 0, stream));
 

@@ -155,9 +155,27 @@ static void pk_block_carve(const rst_block_desc* d, Carve& cv, PkBlockBufs& b) {
     b.mfold = cv.floats((size_t)B * C * C);
 }
 
+// What a training forward pass may keep of a block's attention for its backward pass: the softmax matrices, the
+// normalised Gram matrices and norms they came from, and M_b = Wo blockdiag(softmax) -- a few hundred KB to a few MB per
+// block, against five launches over the whole of q and k to form them again.
+struct KeptAttn { float *attn, *ghat, *nq, *nk, *mfold; };
+static KeptAttn kept_carve(const rst_block_desc* d, Carve& cv) {
+    const size_t BH = (size_t)d->B * d->heads, c = (size_t)(d->C / d->heads);
+    KeptAttn k{};
+    k.attn = cv.floats(BH * c * c); k.ghat = cv.floats(BH * c * c);
+    k.nq = cv.floats((size_t)d->B * d->C); k.nk = cv.floats((size_t)d->B * d->C);
+    k.mfold = cv.floats((size_t)d->B * d->C * d->C);
+    return k;
+}
+static size_t pk_block_kept_bytes(const rst_block_desc* d) {
+    Carve cv(nullptr);
+    kept_carve(d, cv);
+    return cv.total();
+}
+
 // x1 = x + attention(LN1(x));  y = x1 + ffn(LN2(x1))   (model/Restromer.py:163-167), y may alias x
 static int pk_block_fwd(const rst_block_desc* d, const rst_block_params* p, const void* prepared, const bf16_t* x, bf16_t* y,
-                        void* ws, size_t ws_bytes, hipStream_t stream) {
+                        void* kept, void* ws, size_t ws_bytes, hipStream_t stream) {
     RST_REQUIRE(x && y && p, "bf16 block: null operand");
     RST_REQUIRE(p->temperature && p->proj_weight, "bf16 block: null attention parameter");
     RST_REQUIRE(!d->conv_bias || p->proj_bias, "bf16 block: conv_bias set but a bias is null");
@@ -176,6 +194,13 @@ static int pk_block_fwd(const rst_block_desc* d, const rst_block_params* p, cons
         if (!prepared) RST_TRY(pk_block_prepare(d, p, b, stream));
     }
     pk_block_carve(d, cv, b);
+    KeptAttn keep{};
+    if (kept != nullptr) {
+        RST_REQUIRE(aligned16(kept), "bf16 block: the buffer for the kept attention must be 16-byte aligned");
+        Carve ck(kept);
+        keep = kept_carve(d, ck);
+        b.attn = keep.attn; b.mfold = keep.mfold;
+    }
     bf16_t* t = b.buf1; bf16_t* qkv = b.buf2; bf16_t* u = b.buf1; bf16_t* gbuf = b.buf2;
     const int64_t cn = (int64_t)C * N;
 
@@ -208,10 +233,10 @@ static int pk_block_fwd(const rst_block_desc* d, const rst_block_params* p, cons
     }
     if (b.splits > 16) {
         RST_TRY(reduce_slabs3_launch(b.gram_part, b.gram_red, (int64_t)c * c, b.sqq_part, b.sqq_red, c, b.sqk_part, b.sqk_red, c, B * heads, b.splits, stream));
-        RST_TRY(attn_softmax_launch(b.gram_red, b.sqq_red, b.sqk_red, p->temperature, b.attn, nullptr, nullptr, nullptr,
+        RST_TRY(attn_softmax_launch(b.gram_red, b.sqq_red, b.sqk_red, p->temperature, b.attn, keep.ghat, keep.nq, keep.nk,
                                     B, heads, c, 1, stream));
     } else {
-        RST_TRY(attn_softmax_launch(b.gram_part, b.sqq_part, b.sqk_part, p->temperature, b.attn, nullptr, nullptr, nullptr,
+        RST_TRY(attn_softmax_launch(b.gram_part, b.sqq_part, b.sqk_part, p->temperature, b.attn, keep.ghat, keep.nq, keep.nk,
                                     B, heads, c, b.splits, stream));
     }
     RST_TRY(attn_fold_launch(p->proj_weight, b.attn, b.mfold, B, C, heads, c, stream));
@@ -408,7 +433,7 @@ int side_stream_for_current_device(SideStream** out) {
 }  // namespace
 
 static int pk_block_bwd(const rst_block_desc* d, const rst_block_params* p, const void* prepared, const bf16_t* x, const bf16_t* dy,
-                        bf16_t* dx, rst_block_grads* gr, void* ws, size_t ws_bytes, hipStream_t stream) {
+                        bf16_t* dx, rst_block_grads* gr, const void* kept, void* ws, size_t ws_bytes, hipStream_t stream) {
     RST_REQUIRE(x && dy && dx && p && gr, "bf16 block backward: null operand");
     RST_REQUIRE(gr->norm1_weight && gr->norm2_weight && gr->temperature && gr->qkv_weight && gr->qkv_dw_weight && gr->proj_weight &&
                 gr->pin_weight && gr->ffn_dw_weight && gr->pout_weight, "bf16 block backward: null gradient buffer");
@@ -430,6 +455,13 @@ static int pk_block_bwd(const rst_block_desc* d, const rst_block_params* p, cons
         pk_block_carve_prepared(d, cp, b.f);             // the forward pass's prepared weights: nothing changed since
     } else {
         RST_TRY(pk_block_prepare(d, p, b.f, stream));
+    }
+    if (kept != nullptr) {
+        // the forward pass kept its attention: the same matrices the output came from, nothing to form again
+        RST_REQUIRE(aligned16(kept), "bf16 block backward: the kept attention must be 16-byte aligned");
+        Carve ck(const_cast<void*>(kept));
+        const KeptAttn k = kept_carve(d, ck);
+        b.f.attn = k.attn; b.ghat = k.ghat; b.nq = k.nq; b.nk = k.nk; b.f.mfold = k.mfold;
     }
 
     static const bool two_streams = !(getenv("RST_BWD_STREAMS") != nullptr && getenv("RST_BWD_STREAMS")[0] == '0');
@@ -458,6 +490,7 @@ static int pk_block_bwd(const rst_block_desc* d, const rst_block_params* p, cons
         RST_TRY(dw_pk_launch(a, stream));
     }
     {
+        if (kept == nullptr) {
         GramPk g{};
         g.Q = b.qkv; g.Kx = b.qkv + cn; g.bs = 3 * cn; g.cb = c / 8; g.heads = heads; g.B = B; g.N = N;
         g.splits = b.f.splits; g.chunk_px = b.f.chunk; g.partial = b.f.gram_part; g.sqq = b.f.sqq_part; g.sqk = b.f.sqk_part;
@@ -471,6 +504,7 @@ static int pk_block_bwd(const rst_block_desc* d, const rst_block_params* p, cons
                                         B, heads, c, b.f.splits, stream));
         }
         RST_TRY(attn_fold_launch(p->proj_weight, b.f.attn, b.f.mfold, B, C, heads, c, stream));
+        }
         RST_TRY(pk_prep_a_launch(b.f.mfold, (int64_t)C * C, C, nullptr, C, C, NOSEG, NOSEG, b.f.wattn.ntiles, b.f.wattn.KS, b.f.wattn.frag,
                                  (int64_t)b.f.wattn.frag_elems(), B, stream));
         if (cb) RST_TRY(pk_prep_sc_launch(p->proj_weight, C, nullptr, nullptr, p->proj_bias, C, C, NOSEG, NOSEG, b.f.wattn.npos,
@@ -549,12 +583,14 @@ static int pk_block_bwd(const rst_block_desc* d, const rst_block_params* p, cons
         RST_HIP(hipMemcpyAsync(gr->proj_bias, b.red + (size_t)C * 8, sizeof(float) * C, hipMemcpyDeviceToDevice, side));
     }
     RST_TRY(pk_wgrad(b.dx1, cn, C / 8, v, 3 * cn, C / 8, B, N, true, false, b.P, b.part_p, b.part_p_floats, stream));
-    RST_TRY(attn_bwd_small_launch(b.P, p->proj_weight, b.f.attn, b.ghat, b.nq, b.nk, p->temperature, b.Eq, b.Dq, b.Dk,
-                                  b.dGG, b.dtemp_row, b.dtemp_b, b.dwo_b, B, C, heads, c, stream));
-    RST_TRY(fork());                                 // the per-sample sums of the attention's parameter gradients
+    RST_TRY(fork());                                 // P: project_out's own gradient wants nothing else
+    RST_TRY(attn_bwd_wo_launch(b.P, b.f.attn, b.dwo_b, B, C, heads, c, side));
     RST_TRY(reduce_slabs_launch(b.dwo_b, gr->proj_weight, (int64_t)C * C, 1, B, 0, side));
-    RST_TRY(reduce_slabs_launch(b.dtemp_b, gr->temperature, heads, 1, B, 0, side));
     RST_TRY(ln_fwd_pk_launch(x, b.xh, B, C / 8, N, wb, side));      // (the product that read x1's statistics is queued before it)
+    RST_TRY(attn_bwd_small_launch(b.P, p->proj_weight, b.f.attn, b.ghat, b.nq, b.nk, p->temperature, b.Eq, b.Dq, b.Dk,
+                                  b.dGG, b.dtemp_row, b.dtemp_b, B, C, heads, c, stream));
+    RST_TRY(fork());                                 // the per-sample sums of the temperature's gradient
+    RST_TRY(reduce_slabs_launch(b.dtemp_b, gr->temperature, heads, 1, B, 0, side));
     RST_TRY(attn_bwd_mats_launch(b.Eq, b.Dq, b.Dk, b.mats, B, C, c, stream));
     for (int i = 0; i < b.wmat.nslices; ++i)
         RST_TRY(pk_prep_at_launch(b.mats, (int64_t)4 * C * C, 2 * C, 0, 2 * C, NOSEG, NOSEG, 2 * C, NOSEG, NOSEG, b.wmat.kpos0[i],
@@ -628,7 +664,23 @@ int rst_bf16_block_bwd(const rst_block_desc* desc, const rst_block_params* param
                        void* stream) {
     RST_TRY(check_pk_desc(desc));
     return pk_block_bwd(desc, params, prepared, static_cast<const bf16_t*>(x_packed), static_cast<const bf16_t*>(dy_packed),
-                        static_cast<bf16_t*>(dx_packed), grads, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+                        static_cast<bf16_t*>(dx_packed), grads, nullptr, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+size_t rst_bf16_block_kept_bytes(const rst_block_desc* desc) { return check_pk_desc(desc) == RST_OK ? pk_block_kept_bytes(desc) : 0; }
+int rst_bf16_block_fwd_keep(const rst_block_desc* d, const rst_block_params* p, const void* prepared, const void* x_packed, void* y_packed,
+                            void* kept, void* workspace, size_t workspace_bytes, void* stream) {
+    RST_TRY(check_pk_desc(d));
+    RST_REQUIRE(kept != nullptr, "bf16 block: null buffer for the kept attention");
+    return pk_block_fwd(d, p, prepared, static_cast<const bf16_t*>(x_packed), static_cast<bf16_t*>(y_packed), kept, workspace,
+                        workspace_bytes, static_cast<hipStream_t>(stream));
+}
+int rst_bf16_block_bwd_kept(const rst_block_desc* desc, const rst_block_params* params, const void* prepared, const void* x_packed,
+                            const void* dy_packed, void* dx_packed, rst_block_grads* grads, const void* kept, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+    RST_TRY(check_pk_desc(desc));
+    RST_REQUIRE(kept != nullptr, "bf16 block backward: null kept attention");
+    return pk_block_bwd(desc, params, prepared, static_cast<const bf16_t*>(x_packed), static_cast<const bf16_t*>(dy_packed),
+                        static_cast<bf16_t*>(dx_packed), grads, kept, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 int rst_bf16_to_channels_last(const void* x_packed, void* y_nhwc, int32_t B, int32_t C, int64_t N, void* stream) {
@@ -679,8 +731,8 @@ int rst_bf16_block_prepare(const rst_block_desc* d, const rst_block_params* p, v
 int rst_bf16_block_fwd(const rst_block_desc* d, const rst_block_params* p, const void* prepared, const void* x_packed, void* y_packed,
                        void* workspace, size_t workspace_bytes, void* stream) {
     RST_TRY(check_pk_desc(d));
-    return pk_block_fwd(d, p, prepared, static_cast<const bf16_t*>(x_packed), static_cast<bf16_t*>(y_packed), workspace, workspace_bytes,
-                        static_cast<hipStream_t>(stream));
+    return pk_block_fwd(d, p, prepared, static_cast<const bf16_t*>(x_packed), static_cast<bf16_t*>(y_packed), nullptr, workspace,
+                        workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -152,12 +152,24 @@ __global__ void __launch_bounds__(256)
 attn_bwd_cols_kernel(const float* __restrict__ dGG, const float* __restrict__ nk, const float* __restrict__ dtemp_row,
                      float* __restrict__ Dk, float* __restrict__ dtemp_b, int c) {
     __shared__ float red[4];
+    __shared__ float part[4][256];
     const int bh = blockIdx.x, tid = threadIdx.x;
-    for (int j = tid; j < c; j += 256) {
-        float s = 0.f;
-        for (int i = 0; i < c; ++i) s += dGG[((int64_t)bh * c + i) * c + j];
-        const float n = nk[(int64_t)bh * c + j];
-        Dk[(int64_t)bh * c + j] = (n > NORM_EPS) ? -s / (n * n) : 0.f;
+    const int wave = tid >> 6, lane = tid & 63;
+    // a wave takes every fourth row, a lane its columns: c/4 independent loads per lane instead of a chain of c
+    for (int j0 = 0; j0 < c; j0 += 256) {
+        for (int jj = lane; jj < 256 && j0 + jj < c; jj += 64) {
+            float s = 0.f;
+            for (int i = wave; i < c; i += 4) s += dGG[((int64_t)bh * c + i) * c + j0 + jj];
+            part[wave][jj] = s;
+        }
+        __syncthreads();
+        if (j0 + tid < c) {
+            const int j = j0 + tid;
+            const float s = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+            const float n = nk[(int64_t)bh * c + j];
+            Dk[(int64_t)bh * c + j] = (n > NORM_EPS) ? -s / (n * n) : 0.f;
+        }
+        __syncthreads();
     }
     float t = 0.f;
     for (int i = tid; i < c; i += 256) t += dtemp_row[(int64_t)bh * c + i];
@@ -194,7 +206,7 @@ attn_bwd_wo_kernel(const float* __restrict__ P, const float* __restrict__ attn, 
 
 int attn_bwd_small_launch(const float* P, const float* wo, const float* attn, const float* ghat, const float* nq,
                           const float* nk, const float* temperature, float* Eq, float* Dq, float* Dk, float* dGG,
-                          float* dtemp_row, float* dtemp_b, float* dwo_b, int B, int C, int heads, int c,
+                          float* dtemp_row, float* dtemp_b, int B, int C, int heads, int c,
                           hipStream_t stream) {
     {
         // dA[b,h] = Wo[:, h-slice]^T P[b][:, h-slice] into dGG
@@ -217,6 +229,12 @@ int attn_bwd_small_launch(const float* P, const float* wo, const float* attn, co
     hipLaunchKernelGGL(attn_bwd_cols_kernel, dim3((unsigned)(B * heads)), dim3(256), 0, stream, dGG, nk, dtemp_row, Dk,
                        dtemp_b, c);
     RST_LAUNCH_CHECK();
+    return RST_OK;
+}
+
+// dWo_b: reads P and the softmax only, nothing of the chain above -- callers may queue it on another stream
+int attn_bwd_wo_launch(const float* P, const float* attn, float* dwo_b, int B, int C, int heads, int c, hipStream_t stream) {
+    ProfScope prof(stream, "attn_bwd_wo", 2.0 * B * C * C * c, 4.0 * B * (2.0 * C * C + (double)heads * c * c));
     {
         const size_t lds = (size_t)(c * (c + 1) + 16 * c) * sizeof(float);
         RST_REQUIRE(lds <= 160 * 1024, "attention: channels per head %d too large", c);

@@ -157,8 +157,10 @@ int attn_fold_launch(const float* wo, const float* attn, float* mfold, int B, in
 
 int attn_bwd_small_launch(const float* P, const float* wo, const float* attn, const float* ghat, const float* nq,
                           const float* nk, const float* temperature, float* Eq, float* Dq, float* Dk, float* dGG,
-                          float* dtemp_row, float* dtemp_b, float* dwo_b, int B, int C, int heads, int c,
+                          float* dtemp_row, float* dtemp_b, int B, int C, int heads, int c,
                           hipStream_t stream);
+// dWo_b[b] = P[b] blockdiag(softmax)^T per sample (independent of attn_bwd_small_launch's chain)
+int attn_bwd_wo_launch(const float* P, const float* attn, float* dwo_b, int B, int C, int heads, int c, hipStream_t stream);
 
 // ---- reduce.hip ----
 // out[row] = sum over batch and pixels of x[b][row][n]

@@ -133,3 +133,43 @@ def test_block_backward_side_stream_changes_nothing(tmp_path):
                     assert g[k] is None
                 else:
                     assert torch.equal(g[k].cpu(), v), (case, k)
+
+
+@pytest.mark.parametrize("C,heads,hidden,H,W,ln_bias,conv_bias", [CASES[0], CASES[1], CASES[3], CASES[4], CASES[5]])
+def test_block_backward_with_kept_attention(C, heads, hidden, H, W, ln_bias, conv_bias):
+    """rst_bf16_block_fwd_keep + rst_bf16_block_bwd_kept: the backward pass reads the attention the forward pass kept
+    instead of forming it again.  The forward output is that of rst_bf16_block_fwd bit for bit; the gradients agree
+    with the recomputing route to bf16 accuracy (the two see q and k through differently fused kernels) and with the
+    fp32 kernels' gradients within the bounds of the test above."""
+    from superresolution_amd import bf16, ops
+    from superresolution_amd.model.Restromer import TransformerBlock
+    torch.manual_seed(C + hidden + H)
+    blk = TransformerBlock(C, heads, (hidden + 0.5) / C, conv_bias, "WithBias" if ln_bias else "BiasFree").cuda()
+    with torch.no_grad():
+        for n, p in blk.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.3 * torch.randn_like(p))
+    x = torch.randn(2, C, H, W, device="cuda").bfloat16()
+    dy = torch.randn(2, C, H, W, device="cuda").bfloat16()
+    params = blk._params()
+    y_keep, kept = bf16.block_forward_keep(bf16.pack(x), heads, hidden, params)
+    y_plain = bf16.block_(bf16.pack(x), heads, hidden, params)
+    assert torch.equal(y_keep.data, y_plain.data)
+    dxp_k, g_k = bf16.block_backward(bf16.pack(x), bf16.pack(dy), heads, hidden, params, kept_attn=kept)
+    dxp_r, g_r = bf16.block_backward(bf16.pack(x), bf16.pack(dy), heads, hidden, params)
+    dx_k, dx_r = bf16.unpack(dxp_k, torch.float32), bf16.unpack(dxp_r, torch.float32)
+    assert torch.isfinite(dx_k).all()
+    assert float((dx_k - dx_r).norm() / dx_r.norm()) < 1e-2                   # measured <= 3e-3
+    dx_ref, g_ref = ops.block_recompute_backward(x.float(), dy.float(), heads, hidden, params)
+    assert _cos(dx_k, dx_ref) > 0.999 and float((dx_k - dx_ref).norm() / dx_ref.norm()) < 3e-2
+    for name, ref in g_ref.items():
+        if ref is None:
+            assert g_k[name] is None
+            continue
+        if float(ref.norm()) < 1e-6:
+            continue
+        assert torch.isfinite(g_k[name]).all(), name
+        assert float((g_k[name] - g_r[name]).norm() / g_r[name].norm()) < 5e-2, name      # measured <= 1e-2 (temperature)
+        assert _cos(g_k[name], ref) > 0.995 and float((g_k[name] - ref).norm() / ref.norm()) < 0.1, name
+    with pytest.raises(RuntimeError):
+        bf16.block_backward(bf16.pack(x), bf16.pack(dy), heads, hidden, params, kept_attn=kept[:16])
