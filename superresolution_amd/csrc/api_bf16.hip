@@ -409,7 +409,7 @@ int pk_wgrad(const bf16_t* a, int64_t a_bs, int Ab, const bf16_t* bm, int64_t b_
 // everything on the caller's stream.
 struct SideStream {
     hipStream_t s = nullptr;
-    hipEvent_t fork[8] = {};
+    hipEvent_t fork[4] = {};
     hipEvent_t join = nullptr;
 };
 int side_stream_for_current_device(SideStream** out) {
@@ -472,7 +472,7 @@ static int pk_block_bwd(const rst_block_desc* d, const rst_block_params* p, cons
     // what the caller's stream has queued so far is complete before anything queued on the side stream from here on
     auto fork = [&]() -> int {
         if (sd == nullptr) return RST_OK;
-        RST_REQUIRE(nfork < 8, "bf16 block backward: out of fork events");
+        RST_REQUIRE(nfork < 4, "bf16 block backward: out of fork events");
         RST_HIP(hipEventRecord(sd->fork[nfork], stream));
         RST_HIP(hipStreamWaitEvent(side, sd->fork[nfork], 0));
         ++nfork;
@@ -523,7 +523,6 @@ static int pk_block_bwd(const rst_block_desc* d, const rst_block_params* p, cons
         a.x = b.u; a.x_bs = 2 * hn; a.wp = b.f.dw_ffn; a.y = b.d; a.y_bs = 2 * hn;
         a.B = B; a.Cb = 2 * Hp / 8; a.H = d->H; a.W = d->W; a.gate = 0;
         RST_TRY(dw_pk_launch(a, stream));
-        RST_TRY(gate_fwd_pk_launch(b.d, b.g, B, Hp / 8, N, stream));
     }
 
     // ---------------- weights of the data gradients ----------------
@@ -547,26 +546,30 @@ static int pk_block_bwd(const rst_block_desc* d, const rst_block_params* p, cons
     RST_TRY(pk_prep_dw_launch(p->ffn_dw_weight, nullptr, 2 * Hd, Hd, -1, 2 * Hp / 8, b.dw_ffn_flip, stream, 1));
 
     // ---------------- GDFN: y = x1 + Wout (gelu(d1) d2), d = dw(Win LN2(x1)) ----------------
-    RST_TRY(fork());                                 // g (and x1, for the statistics below) are there
+    // Four hand-overs to the side stream per block, not one per operand: recording an event and waiting for it cost
+    // the host about as much as a kernel launch, and the step must not become bound by the host's queueing.
+    RST_TRY(fork());                                 // d (and x1, for the statistics below) are there
+    RST_TRY(gate_fwd_pk_launch(b.d, b.g, B, Hp / 8, N, side));     // g: only project_out's weight gradient reads it
     RST_TRY(pk_wgrad(dy, cn, C / 8, b.g, hn, Hp / 8, B, N, false, cb, b.red, b.part, b.part_floats, side));
     RST_TRY(crop2d_launch(b.red, Hp, gr->pout_weight, C, Hd, side));
     if (cb) RST_HIP(hipMemcpyAsync(gr->pout_bias, b.red + (size_t)C * Hp, sizeof(float) * C, hipMemcpyDeviceToDevice, side));
     RST_TRY(ln_fwd_pk_launch(b.x1, b.xh, B, C / 8, N, wb, side));
     RST_TRY(pk_sliced_gemm(b.wpoutT, dy, cn, b.dg, hn, B, N, 0, stream));
     RST_TRY(gate_bwd_pk_launch(b.dg, b.d, b.dd, B, Hp / 8, N, stream));
-    RST_TRY(fork());                                 // dd
+    {
+        DwPk w{};
+        w.x = b.dd; w.x_bs = 2 * hn; w.wp = b.dw_ffn_flip; w.y = b.du; w.y_bs = 2 * hn;
+        w.B = B; w.Cb = 2 * Hp / 8; w.H = d->H; w.W = d->W; w.gate = 0;
+        RST_TRY(dw_pk_launch(w, stream));
+    }
+    RST_TRY(fork());                                 // dd, du
     {
         DwWgradPk a{};
         a.dy = b.dd; a.dy_bs = 2 * hn; a.x = b.u; a.x_bs = 2 * hn; a.B = B; a.Cb = 2 * Hp / 8; a.H = d->H; a.W = d->W;
         a.partial = b.dw_part;
         RST_TRY(dw_wgrad_pk_launch(a, b.dw_red, side));
         RST_TRY(dw_grad_unpack_launch(b.dw_red, gr->ffn_dw_weight, cb ? gr->ffn_dw_bias : nullptr, 2 * Hd, Hd, -1, 2 * Hp / 8, side));
-        DwPk w{};
-        w.x = b.dd; w.x_bs = 2 * hn; w.wp = b.dw_ffn_flip; w.y = b.du; w.y_bs = 2 * hn;
-        w.B = B; w.Cb = 2 * Hp / 8; w.H = d->H; w.W = d->W; w.gate = 0;
-        RST_TRY(dw_pk_launch(w, stream));
     }
-    RST_TRY(fork());                                 // du
     RST_TRY(pk_wgrad(b.du, 2 * hn, 2 * Hp / 8, b.xh, cn, C / 8, B, N, false, true, b.red, b.part, b.part_floats, side));
     RST_TRY(lnlin_grads_launch(b.red, b.red + (size_t)2 * Hp * C, p->pin_weight, p->norm2_weight, wb ? p->norm2_bias : nullptr, gr->pin_weight,
                                cb ? gr->pin_bias : nullptr, gr->norm2_weight, wb ? gr->norm2_bias : nullptr, 2 * Hd, C, Hd, -1, side));
@@ -575,22 +578,20 @@ static int pk_block_bwd(const rst_block_desc* d, const rst_block_params* p, cons
 
     // ---------------- MDTA: x1 = x + M_b v, M_b = Wo blockdiag(softmax) ----------------
     const bf16_t* q = b.qkv; const bf16_t* k = b.qkv + cn; const bf16_t* v = b.qkv + 2 * cn;
+    RST_TRY(pk_wgrad(b.dx1, cn, C / 8, v, 3 * cn, C / 8, B, N, true, false, b.P, b.part_p, b.part_p_floats, stream));
+    RST_TRY(attn_bwd_small_launch(b.P, p->proj_weight, b.f.attn, b.ghat, b.nq, b.nk, p->temperature, b.Eq, b.Dq, b.Dk,
+                                  b.dGG, b.dtemp_row, b.dtemp_b, B, C, heads, c, stream));
+    RST_TRY(fork());                                 // dx1, P, the per-sample sums of the temperature's gradient
     if (cb) {
         // the projection's bias gradient: the sums of dx1's rows over everything (the product with its own rows is a
         // by-product nobody reads)
-        RST_TRY(fork());                             // dx1
         RST_TRY(pk_wgrad(b.dx1, cn, C / 8, b.dx1, cn, 1, B, N, false, true, b.red, b.part, b.part_floats, side));
         RST_HIP(hipMemcpyAsync(gr->proj_bias, b.red + (size_t)C * 8, sizeof(float) * C, hipMemcpyDeviceToDevice, side));
     }
-    RST_TRY(pk_wgrad(b.dx1, cn, C / 8, v, 3 * cn, C / 8, B, N, true, false, b.P, b.part_p, b.part_p_floats, stream));
-    RST_TRY(fork());                                 // P: project_out's own gradient wants nothing else
     RST_TRY(attn_bwd_wo_launch(b.P, b.f.attn, b.dwo_b, B, C, heads, c, side));
     RST_TRY(reduce_slabs_launch(b.dwo_b, gr->proj_weight, (int64_t)C * C, 1, B, 0, side));
-    RST_TRY(ln_fwd_pk_launch(x, b.xh, B, C / 8, N, wb, side));      // (the product that read x1's statistics is queued before it)
-    RST_TRY(attn_bwd_small_launch(b.P, p->proj_weight, b.f.attn, b.ghat, b.nq, b.nk, p->temperature, b.Eq, b.Dq, b.Dk,
-                                  b.dGG, b.dtemp_row, b.dtemp_b, B, C, heads, c, stream));
-    RST_TRY(fork());                                 // the per-sample sums of the temperature's gradient
     RST_TRY(reduce_slabs_launch(b.dtemp_b, gr->temperature, heads, 1, B, 0, side));
+    RST_TRY(ln_fwd_pk_launch(x, b.xh, B, C / 8, N, wb, side));      // (the product that read x1's statistics is queued before it)
     RST_TRY(attn_bwd_mats_launch(b.Eq, b.Dq, b.Dk, b.mats, B, C, c, stream));
     for (int i = 0; i < b.wmat.nslices; ++i)
         RST_TRY(pk_prep_at_launch(b.mats, (int64_t)4 * C * C, 2 * C, 0, 2 * C, NOSEG, NOSEG, 2 * C, NOSEG, NOSEG, b.wmat.kpos0[i],
@@ -610,19 +611,20 @@ static int pk_block_bwd(const rst_block_desc* d, const rst_block_params* p, cons
         g.a_bs = (int64_t)b.wmfT.frag_elems() / 8;
         RST_TRY(gemm_pk_launch(g, stream));
     }
-    RST_TRY(fork());                                 // dqkv
+    {
+        DwPk w{};
+        w.x = b.dqkv; w.x_bs = 3 * cn; w.wp = b.dw_qkv_flip; w.y = b.dt; w.y_bs = 3 * cn;
+        w.B = B; w.Cb = 3 * C / 8; w.H = d->H; w.W = d->W; w.gate = 0;
+        RST_TRY(dw_pk_launch(w, stream));
+    }
+    RST_TRY(fork());                                 // dqkv, dt
     {
         DwWgradPk a{};
         a.dy = b.dqkv; a.dy_bs = 3 * cn; a.x = b.t; a.x_bs = 3 * cn; a.B = B; a.Cb = 3 * C / 8; a.H = d->H; a.W = d->W;
         a.partial = b.dw_part;
         RST_TRY(dw_wgrad_pk_launch(a, b.dw_red, side));
         RST_TRY(dw_grad_unpack_launch(b.dw_red, gr->qkv_dw_weight, cb ? gr->qkv_dw_bias : nullptr, 3 * C, NOSEG, NOSEG, 3 * C / 8, side));
-        DwPk w{};
-        w.x = b.dqkv; w.x_bs = 3 * cn; w.wp = b.dw_qkv_flip; w.y = b.dt; w.y_bs = 3 * cn;
-        w.B = B; w.Cb = 3 * C / 8; w.H = d->H; w.W = d->W; w.gate = 0;
-        RST_TRY(dw_pk_launch(w, stream));
     }
-    RST_TRY(fork());                                 // dt
     RST_TRY(pk_wgrad(b.dt, 3 * cn, 3 * C / 8, b.xh, cn, C / 8, B, N, false, true, b.red, b.part, b.part_floats, side));
     RST_TRY(lnlin_grads_launch(b.red, b.red + (size_t)3 * C * C, p->qkv_weight, p->norm1_weight, wb ? p->norm1_bias : nullptr, gr->qkv_weight,
                                cb ? gr->qkv_bias : nullptr, gr->norm1_weight, wb ? gr->norm1_bias : nullptr, 3 * C, C, NOSEG, NOSEG, side));
