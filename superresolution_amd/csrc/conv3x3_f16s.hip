@@ -296,6 +296,8 @@ conv3x3_f16s_kernel(Conv3F a) {
 }
 
 int c3_pick_rt(int M) {
+    static const int forced = getenv("RST_CONV_RT") != nullptr ? atoi(getenv("RST_CONV_RT")) : 0;      // A/B runs
+    if (forced >= 1 && forced <= 3) return forced;      // (measured: the highest block that pads least is the fastest here)
     int best = 1;
     int64_t best_pad = INT64_MAX;
     for (int rt = 3; rt >= 1; --rt) {          // 4 would need 171 KB of LDS
