@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -58,6 +59,11 @@ inline int fail(int code, const char* fmt, ...) {
         if (s_ != RST_OK) return s_;  \
     } while (0)
 
+// RST_XCD_WALK=0: kernels that re-read a neighbour's operand keep the plain workgroup order (for A/B timing)
+inline int xcd_walk_enabled() {
+    static const int on = !(getenv("RST_XCD_WALK") != nullptr && getenv("RST_XCD_WALK")[0] == '0');
+    return on;
+}
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline int64_t round_up(int64_t a, int64_t b) { return cdiv(a, b) * b; }
@@ -106,6 +112,16 @@ __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
+}
+
+// Workgroups are dealt to the 8 XCDs round-robin by their linear id (ids 8 apart share an XCD and its L2).  Maps the
+// linear id `bid` of a grid of `n` workgroups to a logical id such that every XCD walks one contiguous range of
+// logical ids in order: neighbouring logical ids then run on one XCD at about the same time, and what they both read
+// comes from HBM once.  A bijection on [0, n) for any n; placement is a matter of speed only.
+__device__ __forceinline__ int64_t xcd_walk(int64_t bid, int64_t n) {
+    const int64_t q = n >> 3, r = n & 7;
+    const int64_t x = bid & 7, local = bid >> 3;
+    return x * q + (x < r ? x : r) + local;
 }
 
 __device__ __forceinline__ float gelu_erf(float x) {

@@ -72,7 +72,7 @@ gemm_f16s_prep_kernel(const float* __restrict__ w, int64_t w_bs, int lda, int tr
 
 template <int RT, bool RES, bool LN>
 __global__ void __launch_bounds__(512)
-gemm_f16s_kernel(GemmNN g, int mblocks, int mtiles, int kch) {
+gemm_f16s_kernel(GemmNN g, int mblocks, int mtiles, int kch, int walk) {
     constexpr int A_FLOATS = 2 * RT * 2 * 256;            // 2 RT tiles x (hi, lo) x 1 KiB
     constexpr int STAGE = A_FLOATS + 16 * GF_XPIECE;
     constexpr int NP = 4 * RT + 16, P = (NP + 7) / 8;     // DMA pieces per chunk, per wave
@@ -83,9 +83,15 @@ gemm_f16s_kernel(GemmNN g, int mblocks, int mtiles, int kch) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lm = lane & 15, kk = lane >> 4;
     const int nq = wave & 3, mh = wave >> 2;
-    const int mb = blockIdx.x % mblocks;
-    const int64_t nt = blockIdx.x / mblocks;
-    const int b1 = blockIdx.y / g.nb2, b2 = blockIdx.y % g.nb2;
+    // the row blocks of one pixel tile read the same pixels: neighbours on one XCD, so the tile leaves HBM once
+    int64_t bx = blockIdx.x, by = blockIdx.y;
+    if (walk) {
+        const int64_t lin = xcd_walk(by * gridDim.x + bx, (int64_t)gridDim.x * gridDim.y);
+        bx = lin % gridDim.x; by = lin / gridDim.x;
+    }
+    const int mb = (int)(bx % mblocks);
+    const int64_t nt = bx / mblocks;
+    const int b1 = (int)(by / g.nb2), b2 = (int)(by % g.nb2);
     const int m0 = mb * 32 * RT;
     const int64_t n0 = nt * GF_BN;
     const char* Af = static_cast<const char*>(g.afrag) + (int64_t)b1 * g.afrag_s1 + (int64_t)b2 * g.afrag_s2;
@@ -352,7 +358,8 @@ int gemm_f16s_launch(const GemmNN& g, hipStream_t stream) {
     KernelSetup su;
     RST_TRY(kernel_setup(kern, 512, lds, &su));
     GemmNN gg = g;
-    void* args[] = {(void*)&gg, (void*)&mblocks, (void*)&mtiles, (void*)&kch};
+    int walk = xcd_walk_enabled();
+    void* args[] = {(void*)&gg, (void*)&mblocks, (void*)&mtiles, (void*)&kch, (void*)&walk};
     RST_HIP(hipLaunchKernel(kern, grid, blk, args, lds, stream));
     RST_LAUNCH_CHECK();
     return RST_OK;

@@ -23,10 +23,11 @@ typedef float gr_f32x2 __attribute__((ext_vector_type(2)));
 // two blocks per CU: gemm_nt_plan aims at 1024 blocks = two full rounds of 512 (three per CU would leave a third round a third full)
 template <int T>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-gram_f16s_kernel(const GemmNT g, int nsub) {
+gram_f16s_kernel(const GemmNT g, int nsub, int walk) {
     __shared__ float red[3][(T * T * 4 + 2 * T) * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int64_t id = blockIdx.x;
+    // the nsub x nsub tile blocks of one (sample, head, split) read the same pixels: neighbours on one XCD
+    int64_t id = walk ? xcd_walk(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
     const int sub = (int)(id % (nsub * nsub)); id /= nsub * nsub;
     const int split = (int)(id % g.splits);
     const int64_t bh = id / g.splits;
@@ -162,9 +163,10 @@ int gram_f16s_launch(const GemmNT& g, hipStream_t stream) {
     ProfScope prof(stream, "gram_f16s", 2.0 * g.M1 * (g.M2 + 2.0) * g.N * nb,
                    4.0 * nb * ((double)(g.M1 + g.M2) * g.N + (double)g.splits * g.M1 * g.M2));
     const dim3 grid((unsigned)items);
-    if (T == 3) hipLaunchKernelGGL(gram_f16s_kernel<3>, grid, dim3(256), 0, stream, g, nsub);
-    else if (T == 2) hipLaunchKernelGGL(gram_f16s_kernel<2>, grid, dim3(256), 0, stream, g, nsub);
-    else hipLaunchKernelGGL(gram_f16s_kernel<1>, grid, dim3(256), 0, stream, g, nsub);
+    const int walk = xcd_walk_enabled();
+    if (T == 3) hipLaunchKernelGGL(gram_f16s_kernel<3>, grid, dim3(256), 0, stream, g, nsub, walk);
+    else if (T == 2) hipLaunchKernelGGL(gram_f16s_kernel<2>, grid, dim3(256), 0, stream, g, nsub, walk);
+    else hipLaunchKernelGGL(gram_f16s_kernel<1>, grid, dim3(256), 0, stream, g, nsub, walk);
     RST_LAUNCH_CHECK();
     return RST_OK;
 }
