@@ -39,7 +39,7 @@ constexpr int C3_SCR_LD = 36;
 
 struct Conv3F {
     const float* x; const void* afrag; const float* bias; float* y;
-    int Cin, Cout, H, W, TW, TH, kch, mblocks, mtiles, tiles_x, tiles_y, mode;
+    int Cin, Cout, H, W, TW, TH, kch, mblocks, mtiles, tiles_x, tiles_y, mode, walk;
 };
 
 __global__ void __launch_bounds__(64)
@@ -79,9 +79,15 @@ conv3x3_f16s_kernel(Conv3F a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lm = lane & 15, kk = lane >> 4;
     const int nq = wave & 3, mh = wave >> 2;
-    const int mb = blockIdx.x % a.mblocks;
-    const int tile = blockIdx.x / a.mblocks;
-    const int b = blockIdx.y;
+    // a tile reads the rows of the tiles above and below it: each XCD takes a contiguous band of tiles
+    int64_t bx = blockIdx.x, by = blockIdx.y;
+    if (a.walk) {
+        const int64_t lin = xcd_walk(by * gridDim.x + bx, (int64_t)gridDim.x * gridDim.y);
+        bx = lin % gridDim.x; by = lin / gridDim.x;
+    }
+    const int mb = (int)(bx % a.mblocks);
+    const int tile = (int)(bx / a.mblocks);
+    const int b = (int)by;
     const int m0 = mb * 32 * RT;
     const int x0 = (tile % a.tiles_x) * a.TW, y0 = (tile / a.tiles_x) * a.TH;
     const int H = a.H, W = a.W, TW = a.TW;
@@ -344,6 +350,7 @@ int conv3x3_f16s_launch(const float* x, const float* w, const float* bias, float
                        a.kch, static_cast<c3_h8*>(ws));
     RST_LAUNCH_CHECK();
     const int64_t gx = (int64_t)a.tiles_x * a.tiles_y * a.mblocks;
+    a.walk = xcd_walk_enabled();
     RST_REQUIRE(gx < (1ll << 31), "conv3x3: grid too large");
     const size_t lds = sizeof(float) * (size_t)(2 * (C3_XS + 3 * 2 * rt * 2 * 256) + 4 * C3_IMGH);
     const void* kern = rt == 1 ? reinterpret_cast<const void*>(&conv3x3_f16s_kernel<1>)

@@ -33,7 +33,7 @@ constexpr int CP_IMG = CP_CHUNKS * 16;         // bytes
 struct Conv3Pk {
     const bf16_t* x; const void* afrag; const float* bias; bf16_t* y;
     int64_t x_bs, y_bs;                        // elements per sample
-    int Cinb, Cout, H, W, TW, TH, kch, mblocks, mtiles, tiles_x, tiles_y, mode;
+    int Cinb, Cout, H, W, TW, TH, kch, mblocks, mtiles, tiles_x, tiles_y, mode, walk;
 };
 
 // frag[mt][q = (dyi * kch + kc) * 3 + dxi][lane] x 16 B: row = permuted position of (mt, lane & 15), k = 32 kc + 8 (lane >> 4) + j
@@ -64,9 +64,15 @@ conv3x3_pk_kernel(Conv3Pk a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lm = lane & 15, kk = lane >> 4;
     const int nq = wave & 3, mh = wave >> 2;
-    const int mb = blockIdx.x % a.mblocks;
-    const int tile = blockIdx.x / a.mblocks;
-    const int b = blockIdx.y;
+    // a tile reads the rows of the tiles above and below it: each XCD takes a contiguous band of tiles
+    int64_t bx = blockIdx.x, by = blockIdx.y;
+    if (a.walk) {
+        const int64_t lin = xcd_walk(by * gridDim.x + bx, (int64_t)gridDim.x * gridDim.y);
+        bx = lin % gridDim.x; by = lin / gridDim.x;
+    }
+    const int mb = (int)(bx % a.mblocks);
+    const int tile = (int)(bx / a.mblocks);
+    const int b = (int)by;
     const int m0 = mb * 32 * RT;
     const int x0 = (tile % a.tiles_x) * a.TW, y0 = (tile / a.tiles_x) * a.TH;
     const int H = a.H, W = a.W, TW = a.TW, TH = a.TH;
@@ -325,6 +331,7 @@ int conv3x3_pk_launch(const bf16_t* x, const float* w, const float* bias, bf16_t
                        a.kch, static_cast<u32x4*>(ws));
     RST_LAUNCH_CHECK();
     const int64_t gx = (int64_t)a.tiles_x * a.tiles_y * a.mblocks;
+    a.walk = xcd_walk_enabled();
     RST_REQUIRE(gx < (1ll << 31), "bf16 conv3x3: grid too large");
     const size_t lds = (size_t)2 * (CP_IMG + 3 * 2 * rt * 1024);
     const void* kern = rt == 2 ? reinterpret_cast<const void*>(&conv3x3_pk_kernel<2>)
