@@ -16,6 +16,20 @@ namespace rst {
 
 constexpr float NORM_EPS = 1e-12f;
 
+// Sum of one element over its slabs, slab 0 first (the order of a plain loop, so the result is the same bits), with
+// the loads of eight slabs in flight at a time: a loop of dependent load + add pays the memory latency once per slab.
+__device__ __forceinline__ float slab_sum(const float* __restrict__ p, int64_t stride, int splits) {
+    float s = 0.f;
+    for (int sp0 = 0; sp0 < splits; sp0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = sp0 + k < splits ? p[(int64_t)(sp0 + k) * stride] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += v[k];
+    }
+    return s;
+}
+
 // One wave per row i of one (b,h).  grid = (ceil(c/4), B*heads), block = 256.
 __global__ void __launch_bounds__(256)
 attn_softmax_kernel(const float* __restrict__ gram_partial,   // [BH][splits][c][c]
@@ -33,8 +47,7 @@ attn_softmax_kernel(const float* __restrict__ gram_partial,   // [BH][splits][c]
     const int bh = blockIdx.y;
     const int h = bh % heads;
     for (int j = tid; j < c; j += 256) {
-        float s = 0.f;
-        for (int sp = 0; sp < splits; ++sp) s += sqk_partial[((int64_t)bh * splits + sp) * c + j];
+        const float s = slab_sum(sqk_partial + (int64_t)bh * splits * c + j, c, splits);
         const float n = fmaxf(sqrtf(s), NORM_EPS);
         nk[j] = n;
         if (nk_out != nullptr && blockIdx.x == 0) nk_out[(int64_t)bh * c + j] = n;
@@ -42,16 +55,14 @@ attn_softmax_kernel(const float* __restrict__ gram_partial,   // [BH][splits][c]
     __syncthreads();
     const int i = blockIdx.x * 4 + wave;
     if (i >= c) return;
-    float sq = 0.f;
-    for (int sp = 0; sp < splits; ++sp) sq += sqq_partial[((int64_t)bh * splits + sp) * c + i];
+    const float sq = slab_sum(sqq_partial + (int64_t)bh * splits * c + i, c, splits);
     const float nq = fmaxf(sqrtf(sq), NORM_EPS);
     if (nq_out != nullptr && lane == 0) nq_out[(int64_t)bh * c + i] = nq;
     const float temp = temperature[h];
     float* row = smem + c + wave * c;
     float mx = -INFINITY;
     for (int j = lane; j < c; j += 64) {
-        float g = 0.f;
-        for (int sp = 0; sp < splits; ++sp) g += gram_partial[(((int64_t)bh * splits + sp) * c + i) * c + j];
+        const float g = slab_sum(gram_partial + ((int64_t)bh * splits * c + i) * c + j, (int64_t)c * c, splits);
         const float gh = g / (nq * nk[j]);
         if (ghat != nullptr) ghat[((int64_t)bh * c + i) * c + j] = gh;
         const float l = gh * temp;
@@ -72,30 +83,47 @@ attn_softmax_kernel(const float* __restrict__ gram_partial,   // [BH][splits][c]
 }
 
 // Mfold[b][m][h*c + j] = sum_i Wo[m][h*c + i] * A[b,h][i][j]
-// grid = (ceil(C/16), heads, B), block = 256: 16 rows m x c columns j.
+// grid = (ceil(C/16), heads, B), block = 256: 16 rows m x c columns j.  A thread owns four rows of one column: per i one
+// read of A (consecutive lanes, consecutive columns) and one 16-byte broadcast read of the transposed weight tile serve
+// four multiply-adds; the sum runs over i in order.
 __global__ void __launch_bounds__(256)
 attn_fold_kernel(const float* __restrict__ wo,      // [C][C]
                  const float* __restrict__ attn,    // [B*heads][c][c]
                  float* __restrict__ mfold,         // [B][C][C]
                  int C, int heads, int c) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];   // A: c*c, W: 16*c
-    float* As = smem;
-    float* Ws = smem + c * c;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // W^T: c x 16, then A: c*c
+    float* Wt = smem;
+    float* As = smem + 16 * c;
     const int tid = threadIdx.x;
     const int m0 = blockIdx.x * 16, h = blockIdx.y, b = blockIdx.z;
     const float* Abh = attn + ((int64_t)b * heads + h) * c * c;
-    for (int e = tid; e < c * c; e += 256) As[e] = Abh[e];
-    for (int e = tid; e < 16 * c; e += 256) {
-        const int r = e / c, i = e % c;
-        Ws[e] = (m0 + r < C) ? wo[(int64_t)(m0 + r) * C + h * c + i] : 0.f;
+    if ((c & 3) == 0 && (reinterpret_cast<uintptr_t>(Abh) & 15) == 0) {
+        for (int e = tid; e < c * c / 4; e += 256)
+            reinterpret_cast<f32x4*>(As)[e] = reinterpret_cast<const f32x4*>(Abh)[e];
+    } else {
+        for (int e = tid; e < c * c; e += 256) As[e] = Abh[e];
     }
+    for (int r = tid >> 4; r < 16; r += 16)
+        for (int i = tid & 15; i < c; i += 16)
+            Wt[i * 16 + r] = (m0 + r < C) ? wo[(int64_t)(m0 + r) * C + h * c + i] : 0.f;
     __syncthreads();
-    for (int e = tid; e < 16 * c; e += 256) {
-        const int r = e / c, j = e % c;
-        if (m0 + r >= C) continue;
-        float s = 0.f;
-        for (int i = 0; i < c; ++i) s = fmaf(Ws[r * c + i], As[i * c + j], s);
-        mfold[((int64_t)b * C + m0 + r) * C + h * c + j] = s;
+    for (int t = tid; t < 4 * c; t += 256) {
+        const int rq = t / c, j = t - rq * c;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* ap = As + j;
+        const f32x4* wp = reinterpret_cast<const f32x4*>(Wt) + rq;
+#pragma unroll 4
+        for (int i = 0; i < c; ++i) {
+            const float a = ap[i * c];
+            const f32x4 w = wp[i * 4];
+            acc.x = fmaf(w.x, a, acc.x); acc.y = fmaf(w.y, a, acc.y);
+            acc.z = fmaf(w.z, a, acc.z); acc.w = fmaf(w.w, a, acc.w);
+        }
+        float* out = mfold + ((int64_t)b * C + m0 + 4 * rq) * C + h * c + j;
+        if (m0 + 4 * rq + 0 < C) out[0] = acc.x;
+        if (m0 + 4 * rq + 1 < C) out[C] = acc.y;
+        if (m0 + 4 * rq + 2 < C) out[2 * (int64_t)C] = acc.z;
+        if (m0 + 4 * rq + 3 < C) out[3 * (int64_t)C] = acc.w;
     }
 }
 
