@@ -239,9 +239,9 @@ static int pk_block_fwd(const rst_block_desc* d, const rst_block_params* p, cons
         RST_TRY(attn_softmax_launch(b.gram_part, b.sqq_part, b.sqk_part, p->temperature, b.attn, keep.ghat, keep.nq, keep.nk,
                                     B, heads, c, b.splits, stream));
     }
-    RST_TRY(attn_fold_launch(p->proj_weight, b.attn, b.mfold, B, C, heads, c, stream));
-    RST_TRY(pk_prep_a_launch(b.mfold, (int64_t)C * C, C, nullptr, C, C, big, big, b.wattn.ntiles, b.wattn.KS, b.wattn.frag,
-                             (int64_t)b.wattn.frag_elems(), B, stream));
+    // M_b = W_o blockdiag(A) leaves the fold kernel as gemm_pk's operand fragments (and in fp32 when the backward keeps it)
+    RST_TRY(attn_fold_frag_launch(p->proj_weight, b.attn, kept != nullptr ? b.mfold : nullptr, b.wattn.frag,
+                                  (int64_t)b.wattn.frag_elems(), b.wattn.ntiles, b.wattn.KS, B, C, heads, c, stream));
     if (cb) RST_TRY(pk_prep_sc_launch(p->proj_weight, C, nullptr, nullptr, p->proj_bias, C, C, big, big, b.wattn.npos,
                                       b.wattn.s, b.wattn.c, stream));
     {

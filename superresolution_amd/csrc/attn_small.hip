@@ -11,6 +11,7 @@
 //   dA = (W_o^T P)_hh, dS = A o (dA - rowsum(dA o A)), dtemp, dGhat, the
 //   matrices that turn q,k into dq,dk, and dW_o.
 #include "kernels.hpp"
+#include "bf16_common.hpp"
 
 namespace rst {
 
@@ -82,14 +83,26 @@ attn_softmax_kernel(const float* __restrict__ gram_partial,   // [BH][splits][c]
     for (int j = lane; j < c; j += 64) attn[((int64_t)bh * c + i) * c + j] = row[j] * inv;
 }
 
+// Element index of (row position m, contraction position k) in the bf16 fragment buffer pk_prep_a_kernel writes:
+// frag[mt][ks][lane][j] with m = 32 (mt>>1) + 8 (rr>>2) + 4 (mt&1) + (rr&3), rr = lane & 15, k = 32 ks + 8 (lane>>4) + j.
+// Rows m, m+1, m+2, m+3 of an aligned group of four are 8 elements apart.
+__device__ __forceinline__ int64_t fold_frag_index(int m, int k, int KS) {
+    const int mt = 2 * (m >> 5) + ((m >> 2) & 1), rr = 4 * ((m >> 3) & 3) + (m & 3);
+    const int ks = k >> 5, lane = 16 * ((k >> 3) & 3) + rr;
+    return (((int64_t)mt * KS + ks) * 64 + lane) * 8 + (k & 7);
+}
+
 // Mfold[b][m][h*c + j] = sum_i Wo[m][h*c + i] * A[b,h][i][j]
-// grid = (ceil(C/16), heads, B), block = 256: 16 rows m x c columns j.  A thread owns four rows of one column: per i one
+// grid = (ceil(rows/16), heads, B), block = 256: 16 rows m x c columns j (rows = C, or the padded row count of the
+// fragment buffer when fragments are written).  A thread owns four rows of one column: per i one
 // read of A (consecutive lanes, consecutive columns) and one 16-byte broadcast read of the transposed weight tile serve
 // four multiply-adds; the sum runs over i in order.
 __global__ void __launch_bounds__(256)
 attn_fold_kernel(const float* __restrict__ wo,      // [C][C]
                  const float* __restrict__ attn,    // [B*heads][c][c]
-                 float* __restrict__ mfold,         // [B][C][C]
+                 float* __restrict__ mfold,         // [B][C][C] or null
+                 bf16_t* __restrict__ frag,         // or null: Mfold[b] as bf16 operand fragments (layout of pk_prep_a_kernel)
+                 int64_t frag_bs, int KS,
                  int C, int heads, int c) {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // W^T: c x 16, then A: c*c
     float* Wt = smem;
@@ -119,11 +132,26 @@ attn_fold_kernel(const float* __restrict__ wo,      // [C][C]
             acc.x = fmaf(w.x, a, acc.x); acc.y = fmaf(w.y, a, acc.y);
             acc.z = fmaf(w.z, a, acc.z); acc.w = fmaf(w.w, a, acc.w);
         }
-        float* out = mfold + ((int64_t)b * C + m0 + 4 * rq) * C + h * c + j;
-        if (m0 + 4 * rq + 0 < C) out[0] = acc.x;
-        if (m0 + 4 * rq + 1 < C) out[C] = acc.y;
-        if (m0 + 4 * rq + 2 < C) out[2 * (int64_t)C] = acc.z;
-        if (m0 + 4 * rq + 3 < C) out[3 * (int64_t)C] = acc.w;
+        if (mfold != nullptr) {
+            float* out = mfold + ((int64_t)b * C + m0 + 4 * rq) * C + h * c + j;
+            if (m0 + 4 * rq + 0 < C) out[0] = acc.x;
+            if (m0 + 4 * rq + 1 < C) out[C] = acc.y;
+            if (m0 + 4 * rq + 2 < C) out[2 * (int64_t)C] = acc.z;
+            if (m0 + 4 * rq + 3 < C) out[3 * (int64_t)C] = acc.w;
+        }
+        if (frag != nullptr) {
+            // rows past C are padding of the fragment buffer: their weights were staged as zeros, so acc is zero
+            uint16_t* fo = reinterpret_cast<uint16_t*>(frag) + (int64_t)b * frag_bs + fold_frag_index(m0 + 4 * rq, h * c + j, KS);
+            fo[0] = to_bf16_bits(acc.x); fo[8] = to_bf16_bits(acc.y); fo[16] = to_bf16_bits(acc.z); fo[24] = to_bf16_bits(acc.w);
+        }
+    }
+    // contraction positions past C (up to a multiple of 32) are padding as well: the last head's blocks clear them
+    if (frag != nullptr && h == heads - 1) {
+        const int kpad = 32 * KS - C;
+        for (int t = tid; t < 16 * kpad; t += 256) {
+            const int r = t / kpad, k = C + t - r * kpad;
+            reinterpret_cast<uint16_t*>(frag)[(int64_t)b * frag_bs + fold_frag_index(m0 + r, k, KS)] = 0;
+        }
     }
 }
 
@@ -290,14 +318,24 @@ int attn_softmax_launch(const float* gram_partial, const float* sqq_partial, con
 }
 
 int attn_fold_launch(const float* wo, const float* attn, float* mfold, int B, int C, int heads, int c, hipStream_t stream) {
+    return attn_fold_frag_launch(wo, attn, mfold, nullptr, 0, 0, 0, B, C, heads, c, stream);
+}
+
+// As attn_fold_launch; with `frag` the folded matrices also (or only, mfold == null) leave as the bf16 operand fragments
+// of gemm_pk (ntiles 16-row tiles, KS 32-column steps per sample, frag_bs elements apart), padding cleared.
+int attn_fold_frag_launch(const float* wo, const float* attn, float* mfold, bf16_t* frag, int64_t frag_bs, int ntiles, int KS,
+                          int B, int C, int heads, int c, hipStream_t stream) {
     const size_t lds = (size_t)(c * c + 16 * c) * sizeof(float);
     RST_REQUIRE(lds <= 160 * 1024, "attention: channels per head %d too large for the fold kernel", c);
+    RST_REQUIRE(mfold != nullptr || frag != nullptr, "attention fold: no output");
+    RST_REQUIRE(frag == nullptr || (c % 8 == 0 && ntiles % 2 == 0 && 16 * ntiles >= C && 32 * KS >= C && 32 * (KS - 1) < C),
+                "attention fold: fragment output needs 8 | channels per head and a fragment buffer that covers C");
     if (lds > 64 * 1024)
         RST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fold_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    dim3 grid((unsigned)cdiv(C, 16), (unsigned)heads, (unsigned)B);
+    dim3 grid((unsigned)(frag != nullptr ? ntiles : cdiv(C, 16)), (unsigned)heads, (unsigned)B);
     ProfScope prof(stream, "attn_fold", 2.0 * B * C * C * c, 4.0 * B * (2.0 * C * C + (double)heads * c * c));
-    hipLaunchKernelGGL(attn_fold_kernel, grid, dim3(256), lds, stream, wo, attn, mfold, C, heads, c);
+    hipLaunchKernelGGL(attn_fold_kernel, grid, dim3(256), lds, stream, wo, attn, mfold, frag, frag_bs, KS, C, heads, c);
     RST_LAUNCH_CHECK();
     return RST_OK;
 }

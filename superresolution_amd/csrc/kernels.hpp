@@ -154,6 +154,8 @@ int attn_softmax_launch(const float* gram_partial, const float* sqq_partial, con
                         const float* temperature, float* attn, float* ghat, float* nq, float* nk,
                         int B, int heads, int c, int splits, hipStream_t stream);
 int attn_fold_launch(const float* wo, const float* attn, float* mfold, int B, int C, int heads, int c, hipStream_t stream);
+int attn_fold_frag_launch(const float* wo, const float* attn, float* mfold, uint16_t* frag, int64_t frag_bs, int ntiles, int KS,
+                          int B, int C, int heads, int c, hipStream_t stream);
 
 int attn_bwd_small_launch(const float* P, const float* wo, const float* attn, const float* ghat, const float* nq,
                           const float* nk, const float* temperature, float* Eq, float* Dq, float* Dk, float* dGG,
