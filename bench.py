@@ -220,6 +220,44 @@ def cpu_baseline(net, budget_s: float = 25.0):
             "gpu_vs_cpu_oracle_max_rel_err": err}
 
 
+def cpu_baseline_train(net, bf16: bool, budget_s: float = 25.0):
+    """The CPU oracle's forward + L1 + backward (the differentiated part of the step of model/train.py:82-90) on the
+    host cores, on a bounded sample of the training workload (1 x 3 x 128 x 128), and the HIP network's loss and global
+    gradient norm on the same sample and parameters against it."""
+    from oracle import restormer_oracle as orc
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items()}
+    gen = torch.Generator().manual_seed(5)
+    x = torch.rand(1, 3, 128, 128, generator=gen)
+    tgt = torch.rand(1, 3, 256, 256, generator=gen)
+
+    def cpu_step():
+        params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        loss = orc.l1_loss(orc.restormer_forward(x, params), tgt)
+        grads = torch.autograd.grad(loss, list(params.values()), allow_unused=True)
+        return float(loss.detach()), float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads if g is not None)))
+
+    ref_loss, ref_norm = cpu_step()             # warm-up
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 5 and (time.perf_counter() - t_start) < budget_s:
+        t0 = time.perf_counter()
+        cpu_step()
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    params = [p for p in net.parameters() if p.requires_grad]
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+        loss = torch.nn.functional.l1_loss(net(x.cuda()).float(), tgt.cuda())
+    grads = torch.autograd.grad(loss, params, allow_unused=True)
+    norm = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads if g is not None)))
+    return {"value": round(128 * 128 / med / 1e6, 4), "unit": "MP/s", "cores": cores, "kind": "port",
+            "sample": f"1x3x128x128 fp32 forward + L1 + backward of the CPU oracle, median of {len(times)} runs, {med:.3f} s each",
+            "gpu_vs_cpu_oracle_loss_rel_err": abs(float(loss.detach()) - ref_loss) / abs(ref_loss),
+            "gpu_vs_cpu_oracle_grad_norm_rel_err": abs(norm - ref_norm) / ref_norm}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -371,6 +409,8 @@ def main():
         out["hip_kernel_ms_per_step"] = round(ktotal, 3)
         if world == 1 and not args.no_cpu_baseline and args.mode == "infer" and args.dtype == "f32":
             out["cpu_baseline"] = cpu_baseline(net)
+        if world == 1 and not args.no_cpu_baseline and args.mode == "train":
+            out["cpu_baseline"] = cpu_baseline_train(net, args.dtype == "bf16")
         print(json.dumps(out), flush=True)
     barrier(world)
     if world > 1:

@@ -364,6 +364,9 @@ def stage(x: torch.Tensor, blocks) -> torch.Tensor:
     for b in blocks:
         if getattr(b, "_pk_cache", None) is None:
             b._pk_cache = PreparedCache()
+        # A training forward prepares the weights afresh: they change every step, and not every optimiser moves the
+        # version counter the cache is keyed on (torch's fused Adam does not).  The backward of this forward reuses them.
+        b._pk_cache.invalidate()
         caches.append(b._pk_cache)
         par = b._params()
         flat.extend(par[n] for n in PARAM_FIELDS)

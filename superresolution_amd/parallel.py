@@ -197,6 +197,11 @@ class DataParallelTrainer:
                 b.flat.div_(self.world)
         torch.nn.utils.clip_grad_norm_(self.params, max_norm=self.max_grad_norm)
         self.optimizer.step()
+        # the fused optimiser updates the parameters without moving their version counters: weights prepared from the
+        # old values (folded LayerNorms, bf16 fragments) must not survive into the next forward or an evaluation
+        invalidate = getattr(self.model, "invalidate_prepared", None)
+        if invalidate is not None:
+            invalidate()
         return loss.detach()
 
 

@@ -99,3 +99,34 @@ def test_bf16_stage_backward_matches_the_fp32_block_gradient():
     assert rel(xa.grad.float(), xb.grad) < 3e-2
     for k, p in blocks.named_parameters():
         assert rel(ga[k], p.grad) < 5e-2, k
+
+
+@pytest.mark.parametrize("autocast", [True, False])
+def test_trainer_steps_leave_no_stale_prepared_weights(autocast):
+    """DataParallelTrainer uses torch's fused Adam, which updates parameters without moving their version counters:
+    after its steps the next forward (training and evaluation, bf16 and fp32) must see the new weights -- the result
+    has to be the one obtained after dropping every prepared-weight cache by hand."""
+    from superresolution_amd.parallel import Collectives, DataParallelTrainer
+    net, x, tgt = _net(recipe.MODEL_CASES[1])
+    trainer = DataParallelTrainer(net, world_size=1, comm=Collectives(eager=False), lr=1e-3)   # steps that matter
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        before = net(x).float()                                   # fills the inference caches with the initial weights
+    for _ in range(2):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            trainer.step(x, tgt)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        got = net(x).float()
+        net.invalidate_prepared()
+        want = net(x).float()
+    # (stale weights would be off by what the steps changed, asserted below to be far more than this)
+    assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    assert float((got - before).abs().max()) > 1e-2 * float(want.abs().max())     # the steps did change the output
+    # and a training forward after a plain fused-optimiser step outside the trainer
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        (net(x) - tgt).abs().mean().backward()
+        opt.step()
+        l_got = float((net(x) - tgt).abs().mean().detach())
+        net.invalidate_prepared()
+        l_want = float((net(x) - tgt).abs().mean().detach())
+    assert abs(l_got - l_want) <= 1e-5 * abs(l_want)
