@@ -126,13 +126,17 @@ static int pk_block_prepare(const rst_block_desc* d, const rst_block_params* p, 
                 "bf16 block: conv_bias set but a bias is null");
     const int C = d->C, Hd = d->hidden, Hp = pad8(Hd);
     const bool cb = d->conv_bias != 0;
-    RST_TRY(pk_weight_prepare(b.wqkv, p->qkv_weight, p->norm1_weight, d->ln_with_bias ? p->norm1_bias : nullptr,
-                              cb ? p->qkv_bias : nullptr, stream));
-    RST_TRY(pk_prep_dw_launch(p->qkv_dw_weight, cb ? p->qkv_dw_bias : nullptr, 3 * C, NOSEG, NOSEG, 3 * C / 8, b.dw_qkv, stream));
-    RST_TRY(pk_weight_prepare(b.wpin, p->pin_weight, p->norm2_weight, d->ln_with_bias ? p->norm2_bias : nullptr,
-                              cb ? p->pin_bias : nullptr, stream));
-    RST_TRY(pk_prep_dw_launch(p->ffn_dw_weight, cb ? p->ffn_dw_bias : nullptr, 2 * Hd, Hd, -1, 2 * Hp / 8, b.dw_ffn, stream));
-    return pk_weight_prepare(b.wpout, p->pout_weight, nullptr, nullptr, cb ? p->pout_bias : nullptr, stream);
+    // all eight preparations of a block in one launch
+    PkPrepJobs jobs;
+    auto weight = [&](const PkWeight& w, const float* src, const float* gamma, const float* beta, const float* bias) {
+        pk_prep_jobs_add_weight(jobs, src, w.K, gamma, beta, bias, w.M, w.seg, w.seg_pad, w.ntiles, w.KS, w.npos, w.frag, w.s, w.c);
+    };
+    weight(b.wqkv, p->qkv_weight, p->norm1_weight, d->ln_with_bias ? p->norm1_bias : nullptr, cb ? p->qkv_bias : nullptr);
+    pk_prep_jobs_add_dw(jobs, p->qkv_dw_weight, cb ? p->qkv_dw_bias : nullptr, 3 * C, NOSEG, NOSEG, 3 * C / 8, b.dw_qkv);
+    weight(b.wpin, p->pin_weight, p->norm2_weight, d->ln_with_bias ? p->norm2_bias : nullptr, cb ? p->pin_bias : nullptr);
+    pk_prep_jobs_add_dw(jobs, p->ffn_dw_weight, cb ? p->ffn_dw_bias : nullptr, 2 * Hd, Hd, -1, 2 * Hp / 8, b.dw_ffn);
+    weight(b.wpout, p->pout_weight, nullptr, nullptr, cb ? p->pout_bias : nullptr);
+    return pk_prep_jobs_launch(jobs, stream);
 }
 
 static void pk_block_carve(const rst_block_desc* d, Carve& cv, PkBlockBufs& b) {

@@ -18,11 +18,10 @@ namespace rst {
 // ---- weight preparation -----------------------------------------------------------------------------------
 // frag[b][mt][ks][lane][j] = A operand of m-tile mt, k-step ks:  row = permuted position, k = 32 ks + 8 (lane>>4) + j
 // position of (mt, rr = lane & 15): 32 (mt>>1) + 8 (rr>>2) + 4 (mt&1) + (rr&3)
-__global__ void __launch_bounds__(256)
-pk_prep_a_kernel(const float* __restrict__ w, int64_t w_bs, int ldw, const float* __restrict__ gamma,
-                 int M, int K, int seg, int seg_pad, int ntiles, int KS, bf16_t* __restrict__ frag, int64_t frag_bs) {
-    const int b = blockIdx.y;
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;          // (mt, ks, lane)
+__device__ __forceinline__ void
+pk_prep_a_body(int bx, int b, const float* __restrict__ w, int64_t w_bs, int ldw, const float* __restrict__ gamma,
+               int M, int K, int seg, int seg_pad, int ntiles, int KS, bf16_t* __restrict__ frag, int64_t frag_bs) {
+    const int64_t e = (int64_t)bx * 256 + threadIdx.x;                  // (mt, ks, lane)
     if (e >= (int64_t)ntiles * KS * 64) return;
     const int lane = (int)(e & 63), ks = (int)((e >> 6) % KS), mt = (int)((e >> 6) / KS);
     const int rr = lane & 15;
@@ -41,14 +40,19 @@ pk_prep_a_kernel(const float* __restrict__ w, int64_t w_bs, int ldw, const float
     }
     *reinterpret_cast<u32x4*>(frag + (int64_t)b * frag_bs + e * 8) = pack8(v);
 }
+__global__ void __launch_bounds__(256)
+pk_prep_a_kernel(const float* __restrict__ w, int64_t w_bs, int ldw, const float* __restrict__ gamma,
+                 int M, int K, int seg, int seg_pad, int ntiles, int KS, bf16_t* __restrict__ frag, int64_t frag_bs) {
+    pk_prep_a_body(blockIdx.x, blockIdx.y, w, w_bs, ldw, gamma, M, K, seg, seg_pad, ntiles, KS, frag, frag_bs);
+}
 
 // s[pos] = sum_k bf16(w[ch][k] gamma[k]) (the rounded values, so that the mean term cancels what the product adds);
 // c[pos] = sum_k w[ch][k] beta[k] + bias[ch];  zero at padding positions.  One wave per position.
-__global__ void __launch_bounds__(256)
-pk_prep_sc_kernel(const float* __restrict__ w, int ldw, const float* __restrict__ gamma, const float* __restrict__ beta,
-                  const float* __restrict__ bias, int M, int K, int seg, int seg_pad, int npos,
-                  float* __restrict__ s, float* __restrict__ c) {
-    const int pos = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+__device__ __forceinline__ void
+pk_prep_sc_body(int bx, const float* __restrict__ w, int ldw, const float* __restrict__ gamma, const float* __restrict__ beta,
+                const float* __restrict__ bias, int M, int K, int seg, int seg_pad, int npos,
+                float* __restrict__ s, float* __restrict__ c) {
+    const int pos = bx * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (pos >= npos) return;
     const int ch = src_channel(pos, seg, seg_pad, M);
     float ss = 0.f, cc = 0.f;
@@ -64,18 +68,40 @@ pk_prep_sc_kernel(const float* __restrict__ w, int ldw, const float* __restrict_
     }
     if (lane == 0) { s[pos] = ss; c[pos] = cc; }
 }
+__global__ void __launch_bounds__(256)
+pk_prep_sc_kernel(const float* __restrict__ w, int ldw, const float* __restrict__ gamma, const float* __restrict__ beta,
+                  const float* __restrict__ bias, int M, int K, int seg, int seg_pad, int npos,
+                  float* __restrict__ s, float* __restrict__ c) {
+    pk_prep_sc_body(blockIdx.x, w, ldw, gamma, beta, bias, M, K, seg, seg_pad, npos, s, c);
+}
 
 // depthwise weights per channel block: 72 taps [tap][8 channels] + 8 biases
-__global__ void __launch_bounds__(256)
-pk_prep_dw_kernel(const float* __restrict__ w, const float* __restrict__ bias, int C, int seg, int seg_pad, int Cb,
-                  float* __restrict__ out, int flip) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void
+pk_prep_dw_body(int bx, const float* __restrict__ w, const float* __restrict__ bias, int C, int seg, int seg_pad, int Cb,
+                float* __restrict__ out, int flip) {
+    const int e = bx * 256 + threadIdx.x;
     if (e >= Cb * 80) return;
     const int cb = e / 80, r = e % 80, tap = r / 8, j = r % 8;
     const int ch = src_channel(cb * 8 + j, seg, seg_pad, C);
     float v = 0.f;
     if (ch >= 0) v = tap < 9 ? w[ch * 9 + (flip ? 8 - tap : tap)] : (bias != nullptr ? bias[ch] : 0.f);
     out[e] = v;
+}
+__global__ void __launch_bounds__(256)
+pk_prep_dw_kernel(const float* __restrict__ w, const float* __restrict__ bias, int C, int seg, int seg_pad, int Cb,
+                  float* __restrict__ out, int flip) {
+    pk_prep_dw_body(blockIdx.x, w, bias, C, seg, seg_pad, Cb, out, flip);
+}
+
+// Several preparations in one launch (all the weights of a block): grid = (blocks of the largest job, jobs).
+__global__ void __launch_bounds__(256)
+pk_prep_jobs_kernel(const PkPrepJobs jobs) {
+    const PkPrepJob& j = jobs.j[blockIdx.y];
+    const int bx = blockIdx.x;
+    if (bx >= j.blocks) return;
+    if (j.kind == 0) pk_prep_a_body(bx, 0, j.w, 0, j.ldw, j.gamma, j.M, j.K, j.seg, j.seg_pad, j.ntiles, j.KS, j.frag, 0);
+    else if (j.kind == 1) pk_prep_sc_body(bx, j.w, j.ldw, j.gamma, j.beta, j.bias, j.M, j.K, j.seg, j.seg_pad, j.npos, j.s, j.c);
+    else pk_prep_dw_body(bx, j.w, j.bias, j.M, j.seg, j.seg_pad, j.Cb, j.out, 0);
 }
 
 int pk_prep_a_launch(const float* w, int64_t w_bs, int ldw, const float* gamma, int M, int K, int seg, int seg_pad,
@@ -90,6 +116,30 @@ int pk_prep_sc_launch(const float* w, int ldw, const float* gamma, const float* 
                       int seg, int seg_pad, int npos, float* s, float* c, hipStream_t stream) {
     hipLaunchKernelGGL(pk_prep_sc_kernel, dim3((unsigned)cdiv(npos, 4)), dim3(256), 0, stream, w, ldw, gamma, beta, bias,
                        M, K, seg, seg_pad, npos, s, c);
+    RST_LAUNCH_CHECK();
+    return RST_OK;
+}
+void pk_prep_jobs_add_weight(PkPrepJobs& jobs, const float* src, int K, const float* gamma, const float* beta, const float* bias,
+                             int M, int seg, int seg_pad, int ntiles, int KS, int npos, bf16_t* frag, float* s, float* c) {
+    PkPrepJob a{};
+    a.kind = 0; a.w = src; a.ldw = K; a.gamma = gamma; a.M = M; a.K = K; a.seg = seg; a.seg_pad = seg_pad;
+    a.ntiles = ntiles; a.KS = KS; a.frag = frag; a.blocks = (int)cdiv((int64_t)ntiles * KS * 64, 256);
+    jobs.j[jobs.n++] = a;
+    PkPrepJob b = a;
+    b.kind = 1; b.beta = beta; b.bias = bias; b.npos = npos; b.s = s; b.c = c; b.blocks = (int)cdiv(npos, 4);
+    jobs.j[jobs.n++] = b;
+}
+void pk_prep_jobs_add_dw(PkPrepJobs& jobs, const float* w, const float* bias, int C, int seg, int seg_pad, int Cb, float* out) {
+    PkPrepJob a{};
+    a.kind = 2; a.w = w; a.bias = bias; a.M = C; a.seg = seg; a.seg_pad = seg_pad; a.Cb = Cb; a.out = out;
+    a.blocks = (int)cdiv(Cb * 80, 256);
+    jobs.j[jobs.n++] = a;
+}
+int pk_prep_jobs_launch(const PkPrepJobs& jobs, hipStream_t stream) {
+    RST_REQUIRE(jobs.n > 0 && jobs.n <= PkPrepJobs::MAX, "weight preparation: %d jobs", jobs.n);
+    int most = 1;
+    for (int i = 0; i < jobs.n; ++i) most = jobs.j[i].blocks > most ? jobs.j[i].blocks : most;
+    hipLaunchKernelGGL(pk_prep_jobs_kernel, dim3((unsigned)most, (unsigned)jobs.n), dim3(256), 0, stream, jobs);
     RST_LAUNCH_CHECK();
     return RST_OK;
 }

@@ -197,6 +197,18 @@ int pk_prep_a_launch(const float* w, int64_t w_bs, int ldw, const float* gamma, 
 int pk_prep_sc_launch(const float* w, int ldw, const float* gamma, const float* beta, const float* bias, int M, int K,
                       int seg, int seg_pad, int npos, float* s, float* c, hipStream_t stream);
 // flip: the taps rotated by 180 degrees (the data gradient of the convolution)
+// Preparations gathered into one launch: a weight (fragments + its s / c vectors = two jobs) or a depthwise tap table.
+struct PkPrepJob {
+    int kind, blocks;                          // 0: fragments, 1: s / c vectors, 2: depthwise taps
+    const float *w, *gamma, *beta, *bias;
+    int ldw, M, K, seg, seg_pad, ntiles, KS, npos, Cb;
+    bf16_t* frag; float *s, *c, *out;
+};
+struct PkPrepJobs { static constexpr int MAX = 8; PkPrepJob j[MAX]; int n = 0; };
+void pk_prep_jobs_add_weight(PkPrepJobs& jobs, const float* src, int K, const float* gamma, const float* beta, const float* bias,
+                             int M, int seg, int seg_pad, int ntiles, int KS, int npos, bf16_t* frag, float* s, float* c);
+void pk_prep_jobs_add_dw(PkPrepJobs& jobs, const float* w, const float* bias, int C, int seg, int seg_pad, int Cb, float* out);
+int pk_prep_jobs_launch(const PkPrepJobs& jobs, hipStream_t stream);
 int pk_prep_dw_launch(const float* w, const float* bias, int C, int seg, int seg_pad, int Cb, float* out, hipStream_t stream,
                       int flip = 0);
 // depthwise 3x3 over `Cb` channel blocks.  gate: every block holds 4 channels of x1 and the same 4 of x2 (segments
