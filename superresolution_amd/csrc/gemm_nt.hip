@@ -47,7 +47,8 @@ gemm_nt_kernel(GemmNT g, int WR, int WC, int rblocks, int cblocks, int SP, int P
     const int stage_floats = PPW * 4 * 256;               // PPW pieces x 4 waves x 256 floats
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    int bid = blockIdx.x;
+    // the row / column blocks of one pixel split read the same pixels: neighbours on one XCD
+    int bid = g.walk ? (int)xcd_walk(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     const int cb = bid % cblocks; bid /= cblocks;
     const int rb = bid % rblocks; bid /= rblocks;
     const int sp = bid % g.splits; bid /= g.splits;
@@ -238,7 +239,8 @@ gemm_nt_generic_kernel(GemmNT g, int WR, int WC, int rblocks, int cblocks) {
     float* Bs = smem + R1 * NT_LD;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    int bid = blockIdx.x;
+    // the row / column blocks of one pixel split read the same pixels: neighbours on one XCD
+    int bid = g.walk ? (int)xcd_walk(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     const int cb = bid % cblocks; bid /= cblocks;
     const int rb = bid % rblocks; bid /= rblocks;
     const int sp = bid % g.splits; bid /= g.splits;
@@ -486,6 +488,7 @@ int gemm_nt_launch(GemmNT g, const NtPlan& p, hipStream_t stream) {
     RST_REQUIRE(g.M1 > 0 && g.M2 > 0 && g.N > 0 && g.nb1 > 0 && g.nb2 > 0, "gemm_nt: empty problem");
     RST_REQUIRE(g.A && g.Bm && g.partial, "gemm_nt: null operand");
     g.splits = p.splits; g.chunk = p.chunk;
+    g.walk = xcd_walk_enabled();
     if (gram_f16s_supported(g)) return gram_f16s_launch(g, stream);        // (RST_F32_MFMA=1 keeps the exact-fp32 kernel)
     const int WR = p.d1.W, WC = p.d2.W;
     const int64_t grid = (int64_t)g.nb1 * g.nb2 * p.splits * p.d1.blocks * p.d2.blocks;

@@ -94,6 +94,7 @@ struct GemmNT {
     float* partial;
     float* sqA_partial;
     float* sqB_partial;
+    int walk = 0;                 // set by the launcher: tile blocks of one pixel split placed on one XCD
 };
 struct NtDim { int T, W, blocks; };
 struct NtPlan { NtDim d1, d2; int splits; int64_t chunk; };
