@@ -301,6 +301,70 @@ conv3x3_f16s_kernel(Conv3F a) {
     }
 }
 
+// ---- few input channels (the patch embedding, 3 -> 48: model/Restromer.py:172-183) ----------------------------------
+// A 32-channel chunk of the implicit GEMM would be nine tenths zeros, so this shape stays on the vector pipe in exact
+// fp32: one thread = 4 consecutive pixels of a row x all output channels, four at a time; its CIN x 3 x 6 input window
+// sits in registers, the weights [ci][dy][dx][Cout] in LDS (one 16-byte broadcast read serves 16 multiply-adds); every
+// store is a float4 of one output plane, consecutive lanes consecutive chunks.
+template <int CIN>
+__global__ void __launch_bounds__(256)
+conv3x3_fewin_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                     float* __restrict__ y, int Cout, int H, int W, int64_t quads) {
+    extern __shared__ __attribute__((aligned(16))) float c3_fewin_w[];
+    for (int e = threadIdx.x; e < CIN * 9 * Cout; e += 256) {
+        const int co = e % Cout, t = e / Cout;
+        c3_fewin_w[e] = w[(int64_t)co * CIN * 9 + t];
+    }
+    __syncthreads();
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= quads) return;
+    const int W4 = W >> 2;
+    const int xq = (int)(q % W4), row = (int)((q / W4) % H);
+    const int64_t b = q / ((int64_t)W4 * H);
+    const int64_t HW = (int64_t)H * W;
+    float in[CIN][3][6];
+#pragma unroll
+    for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int yy = row + dy - 1;
+            const bool rok = yy >= 0 && yy < H;
+            const float* src = x + (b * CIN + ci) * HW + (int64_t)(rok ? yy : row) * W + 4 * xq;
+            const f32x4 mid = *reinterpret_cast<const f32x4*>(src);
+            const float lf = xq > 0 ? src[-1] : 0.f, rt = xq < W4 - 1 ? src[4] : 0.f;
+            in[ci][dy][0] = rok ? lf : 0.f;
+            in[ci][dy][1] = rok ? mid.x : 0.f; in[ci][dy][2] = rok ? mid.y : 0.f;
+            in[ci][dy][3] = rok ? mid.z : 0.f; in[ci][dy][4] = rok ? mid.w : 0.f;
+            in[ci][dy][5] = rok ? rt : 0.f;
+        }
+    float* dst = y + b * Cout * HW + (int64_t)row * W + 4 * xq;
+    for (int co0 = 0; co0 < Cout; co0 += 4) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float bv = bias != nullptr ? bias[co0 + k] : 0.f;
+            acc[k] = f32x4{bv, bv, bv, bv};
+        }
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(&c3_fewin_w[((ci * 3 + dy) * 3 + dx) * Cout + co0]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        acc[k].x = fmaf(w4[k], in[ci][dy][dx + 0], acc[k].x);
+                        acc[k].y = fmaf(w4[k], in[ci][dy][dx + 1], acc[k].y);
+                        acc[k].z = fmaf(w4[k], in[ci][dy][dx + 2], acc[k].z);
+                        acc[k].w = fmaf(w4[k], in[ci][dy][dx + 3], acc[k].w);
+                    }
+                }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *reinterpret_cast<f32x4*>(dst + (int64_t)(co0 + k) * HW) = acc[k];
+    }
+}
+
 int c3_pick_rt(int M) {
     static const int forced = getenv("RST_CONV_RT") != nullptr ? atoi(getenv("RST_CONV_RT")) : 0;      // A/B runs
     if (forced >= 1 && forced <= 3) return forced;      // (measured: the highest block that pads least is the fastest here)
@@ -337,6 +401,23 @@ int conv3x3_f16s_launch(const float* x, const float* w, const float* bias, float
     RST_REQUIRE(aligned16(x) && aligned16(y), "conv3x3: tensors must be 16-byte aligned");
     if (ws == nullptr || ws_bytes < conv3x3_f16s_ws_bytes(Cin, Cout) || !aligned16(ws))
         return fail(RST_ERR_WORKSPACE, "conv3x3: workspace %zu < %zu bytes", ws_bytes, conv3x3_f16s_ws_bytes(Cin, Cout));
+    static const bool fewin_off = getenv("RST_CONV_FEWIN") != nullptr && getenv("RST_CONV_FEWIN")[0] == '0';   // A/B runs
+    if (!fewin_off && mode == 0 && Cin <= 4 && Cout % 4 == 0 && 4 * 9 * Cout * sizeof(float) <= 64 * 1024) {
+        const int64_t quads = (int64_t)B * H * (W / 4);
+        const size_t lds = (size_t)Cin * 9 * Cout * sizeof(float);
+        const double px = (double)B * H * W;
+        ProfScope prof(stream, "conv3x3_fewin", 18.0 * Cin * Cout * px, 4.0 * px * (Cin + Cout));
+        const dim3 grid((unsigned)cdiv(quads, 256));
+        RST_REQUIRE(cdiv(quads, 256) < (1ll << 31), "conv3x3: grid too large");
+        switch (Cin) {
+        case 1: hipLaunchKernelGGL(conv3x3_fewin_kernel<1>, grid, dim3(256), lds, stream, x, w, bias, y, Cout, H, W, quads); break;
+        case 2: hipLaunchKernelGGL(conv3x3_fewin_kernel<2>, grid, dim3(256), lds, stream, x, w, bias, y, Cout, H, W, quads); break;
+        case 3: hipLaunchKernelGGL(conv3x3_fewin_kernel<3>, grid, dim3(256), lds, stream, x, w, bias, y, Cout, H, W, quads); break;
+        default: hipLaunchKernelGGL(conv3x3_fewin_kernel<4>, grid, dim3(256), lds, stream, x, w, bias, y, Cout, H, W, quads); break;
+        }
+        RST_LAUNCH_CHECK();
+        return RST_OK;
+    }
     Conv3F a{};
     a.x = x; a.afrag = ws; a.bias = bias; a.y = y;
     a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.mode = mode;

@@ -197,7 +197,6 @@ int pk_prep_a_launch(const float* w, int64_t w_bs, int ldw, const float* gamma, 
                      int ntiles, int KS, bf16_t* frag, int64_t frag_bs, int nb, hipStream_t stream);
 int pk_prep_sc_launch(const float* w, int ldw, const float* gamma, const float* beta, const float* bias, int M, int K,
                       int seg, int seg_pad, int npos, float* s, float* c, hipStream_t stream);
-// flip: the taps rotated by 180 degrees (the data gradient of the convolution)
 // Preparations gathered into one launch: a weight (fragments + its s / c vectors = two jobs) or a depthwise tap table.
 struct PkPrepJob {
     int kind, blocks;                          // 0: fragments, 1: s / c vectors, 2: depthwise taps
@@ -210,6 +209,7 @@ void pk_prep_jobs_add_weight(PkPrepJobs& jobs, const float* src, int K, const fl
                              int M, int seg, int seg_pad, int ntiles, int KS, int npos, bf16_t* frag, float* s, float* c);
 void pk_prep_jobs_add_dw(PkPrepJobs& jobs, const float* w, const float* bias, int C, int seg, int seg_pad, int Cb, float* out);
 int pk_prep_jobs_launch(const PkPrepJobs& jobs, hipStream_t stream);
+// flip: the taps rotated by 180 degrees (the data gradient of the convolution)
 int pk_prep_dw_launch(const float* w, const float* bias, int C, int seg, int seg_pad, int Cb, float* out, hipStream_t stream,
                       int flip = 0);
 // depthwise 3x3 over `Cb` channel blocks.  gate: every block holds 4 channels of x1 and the same 4 of x2 (segments

@@ -18,6 +18,9 @@ CASES = [  # B, Cin, Cout, H, W, mode, bias
     (2, 3, 48, 8, 128, 0, False), (1, 3, 48, 4, 256, 0, True), (2, 48, 24, 6, 128, 1, False), (1, 96, 48, 4, 64, 1, False),
     (1, 192, 96, 8, 32, 1, False), (1, 384, 768, 4, 32, 2, False), (1, 192, 384, 4, 64, 2, False), (2, 96, 192, 2, 128, 2, False),
     (1, 96, 192, 3, 256, 2, False), (1, 48, 40, 5, 384, 0, True), (1, 33, 20, 4, 32, 2, True), (1, 70, 130, 2, 64, 0, False),
+    # few input channels: the direct fp32 kernel (one row, narrow rows, 1 / 2 / 4 channels, an output count of 4 k)
+    (2, 3, 48, 1, 128, 0, True), (1, 3, 48, 8, 32, 0, False), (1, 1, 8, 4, 64, 0, True), (2, 2, 12, 4, 128, 0, False),
+    (1, 4, 20, 2, 256, 0, True), (1, 3, 6, 4, 64, 0, True),   # 6 outputs: not a multiple of 4, stays on the matrix kernel
 ]
 
 
