@@ -36,3 +36,15 @@ for name, ci, co, s, mode in SHAPES:
     tot[0] += a; tot[1] += b
     print(f"{name:15s} {ci:4d}->{co:4d} @{s:3d}: hip {a:8.1f} us ({fl / a / 1e6:6.1f} TFLOP/s eq.)  miopen conv only {b:8.1f} us")
 print(f"total hip {tot[0]:.0f} us, miopen {tot[1]:.0f} us (+ shuffles)")
+
+# the packed bf16 kernels on the same shapes
+from superresolution_amd import bf16 as pk  # noqa: E402
+tot16 = 0.0
+for name, ci, co, s, mode in SHAPES:
+    x = torch.randn(B, ci, s, s, device="cuda")
+    w = torch.randn(co, ci, 3, 3, device="cuda") / (3.0 * ci ** 0.5)
+    p = pk.pack(x)
+    us = timeit(lambda: pk.conv3x3(p, w, None, mode))
+    tot16 += us
+    print(f"{name:16s} {ci:3d}->{co:4d} @{s:3d}: bf16 packed {us:8.1f} us")
+print(f"total bf16 packed {tot16:.0f} us")
