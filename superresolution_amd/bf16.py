@@ -182,8 +182,16 @@ class PreparedCache:
     def invalidate(self):
         self.key, self.blob = None, None
 
+    @staticmethod
+    def _key(params, device):
+        return tuple((n, t.data_ptr(), t._version) for n, t in params.items() if t is not None) + (str(device),)
+
+    def is_current(self, params, device) -> bool:
+        """True when the kept weights were prepared from exactly these parameter tensors (nothing would be launched)."""
+        return self.key is not None and self.key == self._key(params, device)
+
     def get(self, lib, desc, par, params, device):
-        key = tuple((n, t.data_ptr(), t._version) for n, t in params.items() if t is not None) + (str(device),)
+        key = self._key(params, device)
         if key != self.key:
             nb = lib.rst_bf16_block_prepared_bytes(ctypes.byref(desc))
             blob = torch.empty(nb, dtype=torch.uint8, device=device)

@@ -204,6 +204,9 @@ class Upsample(nn.Module):
         return self.body(x)
 
 
+_SIDE_STREAMS = {}     # device index -> the second stream of two-stream inference (Restormer._forward_two_streams)
+
+
 class Restormer(nn.Module):
     """U-shaped x2 super-resolution network, reference model/Restromer.py:220-433."""
 
@@ -322,6 +325,62 @@ class Restormer(nn.Module):
             raise RuntimeError(f"Restormer expects a 4-D NCHW tensor, got shape {tuple(inp_img.shape)}")
         if inp_img.shape[-2] % 8 or inp_img.shape[-1] % 8:
             raise RuntimeError(f"Restormer needs H and W divisible by 8, got {tuple(inp_img.shape[-2:])}")
+        if self._two_streams_wanted(inp_img):
+            return self._forward_two_streams(inp_img)
+        return self._forward_one(inp_img)
+
+    # Inference of a batch on the bf16 path as two half-batches on two HIP streams.  The kernels of a block alternate
+    # between ones that wait for issue slots / the matrix pipe (the fused 1x1 + depthwise kernels) and ones that wait
+    # for memory (the residual products, the Gram sums); two independent launch sequences, a little out of step, fill
+    # each other's gaps: 16 x 3 x 256^2 takes 16.5 instead of 17.6 ms, and halves that do not fill the chip lose
+    # (2 x 256^2: 6.2 against 5.3 ms), hence the size bound.  The samples of a batch never meet (attention is per
+    # sample), and the result is bit for bit that of the two half-batch calls.
+    # The fp32 path is NOT split: it gained less (35.1 against 36.0 ms), and its results moved (up to 2e-3 at the
+    # headline shape, every run) when kernels of two streams overlapped -- traced to the block path at 192 / 384
+    # channels with the split-f16 product that adds a residual (exact with RST_F16S_MINK above those widths; every
+    # operator and sub-module on its own is exact on two streams), cause not found.  Until it is, the fp32 entry points
+    # of the library should not be driven from two streams at once.
+    two_streams = True                      # per instance or class; RST_TWO_STREAMS=0 in the environment: never
+    two_streams_min_pixels = 4 * 256 * 256  # input pixels per half-batch from which the split pays
+
+    def _two_streams_wanted(self, inp_img) -> bool:
+        import os
+        if not self.two_streams or os.environ.get("RST_TWO_STREAMS") == "0":
+            return False
+        if not inp_img.is_cuda or inp_img.shape[0] < 2 or torch.is_grad_enabled():
+            return False
+        if (inp_img.shape[0] // 2) * inp_img.shape[-2] * inp_img.shape[-1] < self.two_streams_min_pixels:
+            return False
+        if torch.cuda.is_current_stream_capturing():
+            return False
+        # Both halves read the blocks' prepared weights; a cache that is not current would be rebuilt by the first
+        # half on ITS stream while the other reads it.  Such a call runs as one sequence (and leaves the caches current).
+        bf16_path = (inp_img.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and
+                                                          torch.get_autocast_dtype("cuda") == torch.bfloat16))
+        if not (bf16_path and self._bf16_inference_ok(inp_img)):
+            return False
+        for m in self.modules():
+            if isinstance(m, TransformerBlock):
+                cache = getattr(m, "_pk_cache", None)
+                if cache is None or not cache.is_current(m._params(), inp_img.device):
+                    return False
+        return True
+
+    def _forward_two_streams(self, inp_img):
+        cur = torch.cuda.current_stream(inp_img.device)
+        side = _SIDE_STREAMS.get(inp_img.device.index)          # (not on the module: streams do not pickle or deep-copy)
+        if side is None:
+            side = _SIDE_STREAMS[inp_img.device.index] = torch.cuda.Stream(device=inp_img.device)
+        first, second = inp_img.chunk(2)
+        side.wait_stream(cur)                                   # the input (and the prepared weights) are ready there
+        with torch.cuda.stream(side):
+            out2 = self._forward_one(second)
+        out1 = self._forward_one(first)
+        cur.wait_stream(side)
+        out2.record_stream(cur)
+        return torch.cat([out1, out2])
+
+    def _forward_one(self, inp_img):
         if inp_img.dtype == torch.bfloat16 or (inp_img.is_cuda and torch.is_autocast_enabled()
                                                and torch.get_autocast_dtype("cuda") == torch.bfloat16):
             if self._bf16_inference_ok(inp_img):

@@ -539,8 +539,16 @@ class PreparedBlock:
     def invalidate(self):
         self.key, self.blob = None, None
 
+    @staticmethod
+    def _key(tensors, device):
+        return tuple((n, t.data_ptr(), t._version) for n, t in tensors.items() if t is not None) + (str(device),)
+
+    def is_current(self, tensors, device) -> bool:
+        """True when the kept buffer was prepared from exactly these parameter tensors (nothing would be launched)."""
+        return self.key is not None and self.key == self._key(tensors, device)
+
     def get(self, lib, desc, par, tensors, device):
-        key = tuple((n, t.data_ptr(), t._version) for n, t in tensors.items() if t is not None) + (str(device),)
+        key = self._key(tensors, device)
         if key != self.key:
             blob = torch.empty(lib.rst_block_prepared_bytes(ctypes.byref(desc)), dtype=torch.uint8, device=device)
             check(lib.rst_block_prepare(ctypes.byref(desc), ctypes.byref(par), _ptr(blob), _stream()), "rst_block_prepare")
