@@ -381,9 +381,23 @@ def main():
                                "ms_per_step": round(el / args.steps * 1e3, 3), "dtype": "bf16",
                                "note": "same workload, activations stored in bf16 between kernels, fp32 sums and parameters; "
                                        "PSNR within 0.01 dB of the fp32 result (tests/test_gpu_bf16.py)"}
-        with torch.no_grad():
-            if net._two_streams_wanted(xb):
-                out["bf16_storage"]["streams"] = 2       # two half-batches on two HIP streams (Restormer._forward_two_streams)
+        # and once more as two half-batches on two HIP streams (Restormer._forward_two_streams, opt-in)
+        was = net.two_streams
+        net.two_streams = True
+        try:
+            for _ in range(args.warmup):
+                step_bf16()
+            barrier(world)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step_bf16()
+            barrier(world)
+            el2 = max_over_ranks(time.perf_counter() - t0, world)
+        finally:
+            net.two_streams = was
+        out["bf16_storage"]["two_streams"] = {"value": round(world * B * S * S * args.steps / 1e6 / el2, 3), "unit": "MP/s",
+                                              "ms_per_step": round(el2 / args.steps * 1e3, 3),
+                                              "note": "opt-in (model.two_streams = True): the batch as two half-batches on two HIP streams"}
         if rank == 0:
             # kernels of the training path that the inference workload does not launch, at a headline shape:
             # channel LayerNorm forward and backward (model/Restromer.py:26-52) at 16 x 96 x 256 x 256

@@ -336,16 +336,21 @@ class Restormer(nn.Module):
     # (2 x 256^2: 6.2 against 5.3 ms), hence the size bound.  The samples of a batch never meet (attention is per
     # sample), and the result is bit for bit that of the two half-batch calls.
     # The fp32 path is NOT split: it gained less (35.1 against 36.0 ms), and its results moved (up to 2e-3 at the
-    # headline shape, every run) when kernels of two streams overlapped -- traced to the block path at 192 / 384
-    # channels with the split-f16 product that adds a residual (exact with RST_F16S_MINK above those widths; every
-    # operator and sub-module on its own is exact on two streams), cause not found.  Until it is, the fp32 entry points
-    # of the library should not be driven from two streams at once.
-    two_streams = True                      # per instance or class; RST_TWO_STREAMS=0 in the environment: never
+    # headline shape, every run) when kernels of two streams overlapped: in the blocks with 192 / 384 channels the
+    # gated depthwise kernel then produces wrong 4 x 4 strips (its input, project_in's output, is right in memory
+    # afterwards).  The fp32 entry points of the library should not be driven from two streams at once.
+    # Opt-in (model.two_streams = True, or RST_TWO_STREAMS=1 in the environment; RST_TWO_STREAMS=0: never): with two
+    # streams active this platform does not always keep a kernel behind the kernel it depends on -- in fp32 the gated
+    # depthwise kernel at 192 / 384 channels sometimes reads project_in's output before it is there (an event marker
+    # between the two cures most of it) -- and although the bf16 path has been bit-exact in every run so far, that is
+    # an observation, not a guarantee.
+    two_streams = False
     two_streams_min_pixels = 4 * 256 * 256  # input pixels per half-batch from which the split pays
 
     def _two_streams_wanted(self, inp_img) -> bool:
         import os
-        if not self.two_streams or os.environ.get("RST_TWO_STREAMS") == "0":
+        env = os.environ.get("RST_TWO_STREAMS")
+        if env == "0" or not (self.two_streams or env == "1"):
             return False
         if not inp_img.is_cuda or inp_img.shape[0] < 2 or torch.is_grad_enabled():
             return False

@@ -16,6 +16,8 @@ def _net():
     net = Restormer(**case[1])
     net.load_state_dict(sd, strict=True)
     net = net.cuda().eval()
+    assert net.two_streams is False         # opt-in
+    net.two_streams = True
     net.two_streams_min_pixels = 0          # split whatever the size
     return net
 

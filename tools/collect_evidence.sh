@@ -11,11 +11,9 @@ timeout -k 10 400 python3 $root/bench.py > $out/bench.json 2> $out/bench.err
 timeout -k 10 200 python3 $root/bench.py --dtype bf16 --no-cpu-baseline --no-side-runs > $out/bench_bf16.json 2> $out/bench_bf16.err
 timeout -k 10 200 python3 $root/bench.py --mode train --no-cpu-baseline --no-side-runs > $out/bench_train.json 2> $out/bench_train.err
 timeout -k 10 200 python3 $root/bench.py --mode train --dtype bf16 --no-cpu-baseline --no-side-runs > $out/bench_train_bf16.json 2> $out/bench_train_bf16.err
-# per-kernel evidence: the batch as one launch sequence (every kernel alone on the chip, at the full batch), as in the
-# per-kernel pass of bench.py; the bench lines above are the default (two half-batches on two streams where it pays)
+# the opt-in two-stream mode of the bf16 path, then per-kernel evidence with the batch as one launch sequence (the default)
+RST_TWO_STREAMS=1 timeout -k 10 200 python3 $root/bench.py --dtype bf16 --no-cpu-baseline --no-side-runs > $out/bench_bf16_2streams.json 2> $out/bench_bf16_2streams.err
 export RST_TWO_STREAMS=0
-timeout -k 10 200 python3 $root/bench.py --no-cpu-baseline --no-side-runs > $out/bench_1stream.json 2> $out/bench_1stream.err
-timeout -k 10 200 python3 $root/bench.py --dtype bf16 --no-cpu-baseline --no-side-runs > $out/bench_bf16_1stream.json 2> $out/bench_bf16_1stream.err
 common="--steps 5 --warmup 3 --no-cpu-baseline --no-side-runs"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_fp32 -- python3 $root/bench.py $common > $out/kt_fp32.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_bf16 -- python3 $root/bench.py --dtype bf16 $common > $out/kt_bf16.log 2>&1

@@ -21,14 +21,13 @@ def one(pattern):
 
 
 for name, dst in (("bench.json", "bench"), ("bench_bf16.json", "bench_bf16"), ("bench_train.json", "bench_train"),
-                  ("bench_train_bf16.json", "bench_train_bf16"), ("bench_1stream.json", "bench_1stream"),
-                  ("bench_bf16_1stream.json", "bench_bf16_1stream")):
+                  ("bench_train_bf16.json", "bench_train_bf16"), ("bench_bf16_2streams.json", "bench_bf16_2streams")):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(prof, f"{prefix}_{dst}.json"))
 
-TITLES = {"kt_fp32": ("kernel_stats", "RST_TWO_STREAMS=0 python3 bench.py --steps 5 --warmup 3 (fp32 inference, 16x3x256x256, the batch as one launch sequence)"),
-          "kt_bf16": ("bf16_kernel_stats", "RST_TWO_STREAMS=0 python3 bench.py --dtype bf16 --steps 5 --warmup 3 (bf16-storage inference, 16x3x256x256, the batch as one launch sequence)"),
+TITLES = {"kt_fp32": ("kernel_stats", "python3 bench.py --steps 5 --warmup 3 (fp32 inference, 16x3x256x256)"),
+          "kt_bf16": ("bf16_kernel_stats", "python3 bench.py --dtype bf16 --steps 5 --warmup 3 (bf16-storage inference, 16x3x256x256)"),
           "kt_train": ("train_kernel_stats", "python3 bench.py --mode train --steps 5 --warmup 3 (fp32 training step, 8x3x128x128)"),
           "kt_train_bf16": ("train_bf16_kernel_stats", "python3 bench.py --mode train --dtype bf16 --steps 5 --warmup 3 (bf16 training step, 8x3x128x128)")}
 for d, (dst, what) in TITLES.items():
