@@ -427,14 +427,19 @@ def main():
         if args.mode == "infer":
             with torch.no_grad():
                 split = bool(net._two_streams_wanted(x))
-        was = getattr(net, "two_streams", False)
+        was, was_env = getattr(net, "two_streams", False), os.environ.get("RST_TWO_STREAMS")
         net.two_streams = False
+        os.environ["RST_TWO_STREAMS"] = "0"
         try:
             if split:
                 step()
             prof = kernel_profile(step)
         finally:
             net.two_streams = was
+            if was_env is None:
+                del os.environ["RST_TWO_STREAMS"]
+            else:
+                os.environ["RST_TWO_STREAMS"] = was_env
         roof, breakdown, ktotal = roofline_from(prof, lambda name: measured_traffic(name, B, S, args.mode, args.dtype))
         if split:
             roof["note"] = ("kernel timings: the batch as one launch sequence; the timed steps overlap two half-batches "
