@@ -22,6 +22,19 @@
  *    validated before anything is launched.
  *  - Calls on different devices/streams are independent; a workspace must not
  *    be shared by calls that may overlap in time.
+ *  - Keep the work of one GPU on ONE stream unless you have checked the overlap
+ *    yourself.  Ordering inside a stream is sound on MI355X (a kernel trace of
+ *    two busy streams shows no kernel starting before its predecessor ended),
+ *    but a wave that issues v_mfma_f32_16x16x32_f16/_bf16 back to back can make
+ *    a wave of a kernel from ANOTHER stream on the same compute unit lose lanes
+ *    48..63 of one multiply-add of a dependent chain; most products here are
+ *    such waves.  tools/two_stream_repro.hip shows it without this library.
+ *  - One exception to "everything on `stream`, nothing created": with
+ *    RST_BWD_STREAMS=1 in the environment (off by default, for the reason
+ *    above) rst_bf16_block_bwd / _bwd_kept enqueue their parameter gradients on
+ *    a second stream owned by the library (one per device, created with four
+ *    events on the first such call: not capture-safe) and make `stream` wait
+ *    for it before they return; concurrent callers on one device take turns.
  */
 #ifndef RESTORMER_HIP_H
 #define RESTORMER_HIP_H
@@ -44,6 +57,11 @@ enum rst_status {
 int rst_version(void);
 /* Message of the last failure on this thread ("" if none). */
 const char* rst_last_error(void);
+/* 1 if this process runs the parameter gradients of rst_bf16_block_bwd on the  */
+/* library's own second stream (RST_BWD_STREAMS=1 in the environment when the   */
+/* library first looked), 0 (the default) if every call keeps to its `stream`.  */
+/* No counterpart in the reference, which never names a stream.                  */
+int rst_bwd_side_stream_enabled(void);
 
 /* ------------------------------------------------------------------------- */
 /* Shapes and parameters of one TransformerBlock                              */

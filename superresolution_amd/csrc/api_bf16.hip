@@ -406,29 +406,46 @@ int pk_wgrad(const bf16_t* a, int64_t a_bs, int Ab, const bf16_t* bm, int64_t b_
 
 // The backward pass of a block is two kinds of work: the chain of data gradients (each kernel waits for the one before
 // it) and the parameter gradients (products over the pixels, slab sums, small rearrangements), which only READ what
-// the chain leaves behind.  At training sizes most of these kernels fill a fraction of the chip, so the parameter
-// gradients run on a second stream of the library's own, one per device: it waits for an event the caller's stream
-// records when an operand is ready, and the caller's stream waits for it once, before the call returns.  Calls that
-// overlap on one device share that stream (ordering stays correct, the overlap is lost).  RST_BWD_STREAMS=0 keeps
-// everything on the caller's stream.
+// the chain leaves behind.  At training sizes most of these kernels fill a fraction of the chip, so with
+// RST_BWD_STREAMS=1 the parameter gradients run on a second stream of the library's own, one per device: it waits for
+// an event the caller's stream records when an operand is ready, and the caller's stream waits for it once, before the
+// call returns.  OFF by default: on MI355X a wave that issues v_mfma_f32_16x16x32_{f16,bf16} back to back can make a
+// wave of ANOTHER dispatch on the same CU lose lanes 48..63 of one multiply-add of a dependent chain (measured with
+// tools/two_stream_repro.hip, no library code involved; never seen between waves of one dispatch), and the weight
+// gradient products on the side stream are exactly such waves beside the depthwise and LayerNorm kernels of the chain.
+// With the switch on, the stream and its events are shared by every caller on the device, so a call holds the
+// device's mutex from its first hand-over to its join: concurrent callers on one device take turns.
+bool bwd_side_stream_enabled() {
+    static const bool on = getenv("RST_BWD_STREAMS") != nullptr && getenv("RST_BWD_STREAMS")[0] == '1';
+    return on;
+}
 struct SideStream {
     hipStream_t s = nullptr;
     hipEvent_t fork[4] = {};
     hipEvent_t join = nullptr;
+    std::mutex in_use;            // held by the one call that is handing work to `s`
 };
 int side_stream_for_current_device(SideStream** out) {
     static std::mutex mu;
-    static std::map<int, SideStream> per_device;
+    static std::map<int, SideStream> per_device;         // node-based: the addresses handed out stay valid
     int dev = 0;
     RST_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(mu);
     auto it = per_device.find(dev);
     if (it == per_device.end()) {
-        SideStream sd;
-        RST_HIP(hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking));
-        for (auto& e : sd.fork) RST_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        RST_HIP(hipEventCreateWithFlags(&sd.join, hipEventDisableTiming));
-        it = per_device.emplace(dev, sd).first;
+        SideStream& sd = per_device[dev];
+        if (hipStreamCreateWithFlags(&sd.s, hipStreamNonBlocking) != hipSuccess) {
+            per_device.erase(dev);
+            return fail(RST_ERR_HIP, "bf16 block backward: cannot create the side stream");
+        }
+        bool ok = true;
+        for (auto& e : sd.fork) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            per_device.erase(dev);
+            return fail(RST_ERR_HIP, "bf16 block backward: cannot create the side stream's events");
+        }
+        it = per_device.find(dev);
     }
     *out = &it->second;
     return RST_OK;
@@ -468,9 +485,10 @@ static int pk_block_bwd(const rst_block_desc* d, const rst_block_params* p, cons
         b.f.attn = k.attn; b.ghat = k.ghat; b.nq = k.nq; b.nk = k.nk; b.f.mfold = k.mfold;
     }
 
-    static const bool two_streams = !(getenv("RST_BWD_STREAMS") != nullptr && getenv("RST_BWD_STREAMS")[0] == '0');
     SideStream* sd = nullptr;
-    if (two_streams) RST_TRY(side_stream_for_current_device(&sd));
+    if (bwd_side_stream_enabled()) RST_TRY(side_stream_for_current_device(&sd));
+    std::unique_lock<std::mutex> turn;
+    if (sd != nullptr) turn = std::unique_lock<std::mutex>(sd->in_use);
     const hipStream_t side = sd ? sd->s : stream;
     int nfork = 0;
     // what the caller's stream has queued so far is complete before anything queued on the side stream from here on
@@ -649,6 +667,8 @@ static int pk_block_bwd(const rst_block_desc* d, const rst_block_params* p, cons
 using namespace rst;
 
 extern "C" {
+
+int rst_bwd_side_stream_enabled(void) { return bwd_side_stream_enabled() ? 1 : 0; }
 
 size_t rst_bf16_packed_bytes(int32_t B, int32_t C, int64_t N) {
     if (B <= 0 || C <= 0 || N <= 0) return 0;

@@ -16,6 +16,7 @@ Nothing here depends on the HIP kernels: both classes drive whatever
 from __future__ import annotations
 
 import math
+import os
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
@@ -109,9 +110,16 @@ class DataParallelTrainer:
     def __init__(self, model: nn.Module, world_size: Optional[int] = None, lr: float = 1e-4, weight_decay: float = 1e-6,
                  max_grad_norm: float = 1.0, bucket_mb: float = 25.0,
                  loss_fn: Callable[[torch.Tensor, torch.Tensor], torch.Tensor] = F.l1_loss,
-                 process_group=None, comm: Optional[Collectives] = None):
+                 process_group=None, comm: Optional[Collectives] = None, overlap: Optional[bool] = None):
         self.model = model
         self.comm = _comm(comm, process_group)
+        # overlap=True starts a bucket's all-reduce from the backward pass as soon as its last gradient is there;
+        # False (the default; RST_DP_OVERLAP=1 flips it) starts them after the backward pass.  The collective's kernels
+        # run on RCCL's own stream: overlapped, they share compute units with the backward's matrix kernels, and on
+        # MI355X dense v_mfma_f32_16x16x32 waves were measured to corrupt a dependent multiply-add chain of a kernel
+        # from another stream (tools/two_stream_repro.hip).  Sequenced, the exposed time is the all-reduce itself
+        # (73.7 MB of fp32 gradients: a few hundred microseconds over xGMI) and nothing shares the chip with it.
+        self.overlap = (os.environ.get("RST_DP_OVERLAP", "0") == "1") if overlap is None else bool(overlap)
         self.world = world_size if world_size is not None else self.comm.world_size()
         self.max_grad_norm = max_grad_norm
         self.loss_fn = loss_fn
@@ -169,7 +177,7 @@ class DataParallelTrainer:
             v.copy_(p.grad)
             p.grad = v
         b.pending -= 1
-        if b.pending == 0:
+        if b.pending == 0 and self.overlap:
             b.handle = self.comm.all_reduce(b.flat, async_op=True)
 
     def zero_grad(self):

@@ -78,3 +78,19 @@ def test_cpu_tensors_fail_loudly():
     blk = TransformerBlock(12, 1, 1.25, False, "WithBias")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         blk(torch.randn(1, 12, 4, 4))
+
+
+def test_one_stream_is_the_default(monkeypatch):
+    """The library and the trainer keep a GPU's work on one stream unless asked: dense v_mfma_f32_16x16x32 waves were
+    measured to corrupt a dependent multiply-add chain of a kernel from another stream on MI355X
+    (tools/two_stream_repro.hip), so every overlap of two launch sequences is opt-in."""
+    import torch.nn as nn
+    from superresolution_amd import _lib
+    from superresolution_amd.model.Restromer import Restormer
+    from superresolution_amd.parallel import DataParallelTrainer
+    monkeypatch.delenv("RST_BWD_STREAMS", raising=False)
+    monkeypatch.delenv("RST_DP_OVERLAP", raising=False)
+    monkeypatch.delenv("RST_TWO_STREAMS", raising=False)
+    assert _lib.load().rst_bwd_side_stream_enabled() == 0
+    assert Restormer.two_streams is False
+    assert DataParallelTrainer(nn.Linear(2, 2), world_size=1).overlap is False

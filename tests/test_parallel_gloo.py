@@ -45,7 +45,7 @@ def _init(rank, world, port):
     torch.set_num_threads(1)
 
 
-def _dp_worker(rank, world, port, out_path):
+def _dp_worker(rank, world, port, out_path, overlap):
     _init(rank, world, port)
     torch.manual_seed(0)
     net = _TinySR()
@@ -53,7 +53,7 @@ def _dp_worker(rank, world, port, out_path):
         with torch.no_grad():
             for p in net.parameters():
                 p.add_(1.0)
-    trainer = DataParallelTrainer(net, bucket_mb=0.001)        # tiny buckets -> several all-reduces
+    trainer = DataParallelTrainer(net, bucket_mb=0.001, overlap=overlap)        # tiny buckets -> several all-reduces
     assert len(trainer.buckets) > 1
     g = torch.Generator().manual_seed(5)
     x = torch.rand(4, 3, 8, 8, generator=g)
@@ -70,10 +70,12 @@ def _dp_worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_data_parallel_matches_single_process(tmp_path):
-    """2 ranks x batch 2 == 1 process x batch 4 (L1 mean => averaged gradients), incl. clip + Adam."""
+@pytest.mark.parametrize("overlap", [False, True])
+def test_data_parallel_matches_single_process(tmp_path, overlap):
+    """2 ranks x batch 2 == 1 process x batch 4 (L1 mean => averaged gradients), incl. clip + Adam; with the bucket
+    all-reduces after the backward pass (the default) and started from inside it."""
     out = str(tmp_path / "dp.pt")
-    spawn_bounded(_dp_worker, (2, _free_port(), out), 2)
+    spawn_bounded(_dp_worker, (2, _free_port(), out, overlap), 2)
     got = torch.load(out, weights_only=True)
     torch.manual_seed(0)
     net = _TinySR()
