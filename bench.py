@@ -258,6 +258,59 @@ def cpu_baseline_train(net, bf16: bool, budget_s: float = 25.0):
             "gpu_vs_cpu_oracle_grad_norm_rel_err": abs(norm - ref_norm) / ref_norm}
 
 
+def _timed(step, steps, warmup, world):
+    for _ in range(warmup):
+        step()
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier(world)
+    return max_over_ranks(time.perf_counter() - t0, world) / steps
+
+
+def side_train_bf16(dev, rank, world, steps=8, warmup=3, B=8, S=128):
+    """BASELINE config 3 beside the default line: the bf16 training step (forward, L1, backward, gradient all-reduce
+    over RCCL, division by the world size, clip, Adam) on 8 x 3 x 128 x 128 per GPU, and the same step with the
+    collectives replaced by no-ops -- the difference is what the exchange costs a step."""
+    from superresolution_amd.parallel import Collectives, DataParallelTrainer, NullCollectives
+    gen = torch.Generator(device=dev).manual_seed(200 + rank)
+    x = torch.rand(B, 3, S, S, device=dev, generator=gen)
+    tgt = torch.rand(B, 3, 2 * S, 2 * S, device=dev, generator=gen)
+    res = {}
+    for name, comm in (("rccl", Collectives(eager=True)), ("no_exchange", NullCollectives(max(world, 2)))):
+        net = build_model(0).to(dev)
+        trainer = DataParallelTrainer(net, world_size=world, comm=comm)
+
+        def step():
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                return trainer.step(x, tgt)
+        res[name] = _timed(step, steps, warmup, world)
+        del trainer, net
+    return {"value": round(world * B * S * S / res["rccl"] / 1e6, 3), "unit": "MP/s", "ms_per_step": round(res["rccl"] * 1e3, 3),
+            "ms_per_step_without_exchange": round(res["no_exchange"] * 1e3, 3),
+            "exposed_allreduce_ms": round((res["rccl"] - res["no_exchange"]) * 1e3, 3), "scaling": "weak", "dtype": "bf16",
+            "workload": f"bf16 training step, {B}x3x{S}x{S} per GPU, 73.7 MB fp32 gradient all-reduce in ~25 MB buckets "
+                        f"after the backward pass (RST_DP_OVERLAP=1: from inside it)", "steps": steps, "warmup": warmup}
+
+
+def side_tiled_2048(net, dev, rank, world, steps=3, warmup=1):
+    """BASELINE config 4 beside the default line: one 2048 x 2048 image in 256-pixel tiles + 32 pixels of overlap,
+    tile t on rank t mod world, the cores gathered on rank 0 (bf16 storage path)."""
+    from superresolution_amd.parallel import Collectives, tiled_inference
+    img = torch.rand(1, 3, 2048, 2048, device=dev, generator=torch.Generator(device=dev).manual_seed(300)).bfloat16()
+    comm = Collectives(eager=True)
+    net.eval()
+
+    def step():
+        with torch.no_grad():
+            return tiled_inference(net, img, tile=256, overlap=32, rank=rank, world=world, tile_batch=16, comm=comm)
+    t = _timed(step, steps, warmup, world)
+    return {"value": round(2048 * 2048 / t / 1e6, 3), "unit": "MP/s of image pixels", "ms_per_image": round(t * 1e3, 2),
+            "scaling": "strong", "dtype": "bf16", "workload": "one 1x3x2048x2048 image, 64 windows of up to 320 px dealt to the ranks, "
+            "output gathered on rank 0", "steps": steps, "warmup": warmup}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -398,6 +451,14 @@ def main():
         out["bf16_storage"]["two_streams"] = {"value": round(world * B * S * S * args.steps / 1e6 / el2, 3), "unit": "MP/s",
                                               "ms_per_step": round(el2 / args.steps * 1e3, 3),
                                               "note": "opt-in (model.two_streams = True): the batch as two half-batches on two HIP streams"}
+        import torch.distributed as dist
+        if dist.is_initialized():
+            # Launched under torch.distributed.run: the default line also carries the two workloads whose data path has
+            # an exchange, run through RCCL as they are (also with one rank), so that a 1/2/4/8-GPU sweep of the default
+            # command records them: BASELINE config 3 (bf16 training step, gradient all-reduce) and config 4 (one
+            # 2048 x 2048 image in tiles dealt to the ranks, cores gathered on rank 0).  Never `value`.
+            out["train_bf16"] = side_train_bf16(dev, rank, world)
+            out["tiled_2048"] = side_tiled_2048(net, dev, rank, world)
         if rank == 0:
             # kernels of the training path that the inference workload does not launch, at a headline shape:
             # channel LayerNorm forward and backward (model/Restromer.py:26-52) at 16 x 96 x 256 x 256

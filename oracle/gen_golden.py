@@ -4,7 +4,7 @@ TEST INFRASTRUCTURE ONLY.  Runs in the build container, where the reference
 checkout is mounted read-only; the GPU box never sees the reference, only the
 .npz files written here.  Usage (from the repo root):
 
-    PYTHONDONTWRITEBYTECODE=1 python -m oracle.gen_golden [/root/reference]
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.gen_golden [/root/reference] [--allgrads-only]
 
 For every case in ``oracle/recipe.py`` the reference module is constructed with
 its own constructor, loaded (strict) with the recipe's state-dict -- which also
@@ -23,7 +23,8 @@ import torch
 from . import recipe
 from . import restormer_oracle as orc
 
-REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
+_paths = [a for a in sys.argv[1:] if not a.startswith("--")]
+REF = _paths[0] if _paths else "/root/reference"
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
@@ -133,6 +134,30 @@ def gen_models(ref):
         print(f"model_{tag}: loss {loss.item():.6f} fp32-vs-fp64 maxrel {_maxrel(out32.double(), out):.2e}")
 
 
+ALLGRADS_COUNT = 1024      # elements pinned per parameter tensor in the every-tensor gradient fixture
+
+
+def gen_model_grads_all(ref):
+    """Every parameter gradient of the dim-48 network (loss = L1 against the recipe's target, fp64 reference module):
+    tensors up to ALLGRADS_COUNT elements in full (all temperatures and LayerNorm parameters), the others as a fixed
+    sub-sample of that many elements.  tests/test_gpu_bf16_train.py holds the bf16 training path against it tensor by
+    tensor; model_<tag>.npz keeps only 36 tensors' sub-samples."""
+    case = recipe.MODEL_CASES[1]
+    tag, kwargs, shape = case
+    sd, x, tgt = recipe.model_case_tensors(case, torch.float64)
+    net = ref.Restormer(**kwargs).double()
+    net.load_state_dict(sd, strict=True)
+    loss = (net(x) - tgt).abs().mean()
+    loss.backward()
+    store = {"loss": np.float64(loss.item())}
+    for k, p in net.named_parameters():
+        a = p.grad.detach().cpu().numpy().reshape(-1)
+        store["g/" + k] = a[recipe.subsample_index(a.size, count=ALLGRADS_COUNT)].astype(np.float32)
+        store["gl2/" + k] = np.float64(np.sqrt((a * a).sum()))
+    np.savez_compressed(os.path.join(OUT, f"model_{tag}_allgrads.npz"), **store)
+    print(f"model_{tag}_allgrads: {len(store)} arrays, loss {loss.item():.6f}")
+
+
 def gen_train(ref):
     """Three optimiser steps of the reference module with the stock optimiser,
     in the order of model/train.py:82-90, on the dim=12 default network."""
@@ -172,8 +197,12 @@ def main():
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
     ref = _import_reference()
+    if "--allgrads-only" in sys.argv:          # adds the every-tensor gradient fixture without touching the others
+        gen_model_grads_all(ref)
+        return
     gen_blocks(ref)
     gen_models(ref)
+    gen_model_grads_all(ref)
     gen_train(ref)
 
 

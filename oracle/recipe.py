@@ -108,7 +108,7 @@ def model_case_tensors(case, dtype=torch.float32):
     return sd, x, tgt
 
 
-def subsample_index(numel: int, seed: int = 7) -> np.ndarray:
-    if numel <= SUBSAMPLE:
+def subsample_index(numel: int, seed: int = 7, count: int = SUBSAMPLE) -> np.ndarray:
+    if numel <= count:
         return np.arange(numel)
-    return np.sort(np.random.RandomState(seed + numel % 9973).choice(numel, SUBSAMPLE, replace=False))
+    return np.sort(np.random.RandomState(seed + numel % 9973).choice(numel, count, replace=False))

@@ -141,6 +141,19 @@ class TransformerBlock(nn.Module):
             "pout_weight": f.project_out.weight, "pout_bias": f.project_out.bias,
         }
 
+    def invalidate_prepared(self):
+        for name in ("_pk_cache", "_f32_cache"):
+            cache = getattr(self, name, None)
+            if cache is not None:
+                cache.invalidate()
+
+    def train(self, mode: bool = True):
+        # The prepared weights are keyed on the parameters' version counters, which fused optimisers and writes through
+        # .data do not move.  Every switch between training and evaluation (model.eval() in front of a validation
+        # pass, model.train() after it) drops them, so an evaluation never runs on the weights of an earlier step.
+        self.invalidate_prepared()
+        return super().train(mode)
+
     def forward(self, x):
         if getattr(self, "_f32_cache", None) is None:
             self._f32_cache = ops.PreparedBlock()
@@ -245,13 +258,12 @@ class Restormer(nn.Module):
         self.output = nn.Conv2d(dim, out_channels, kernel_size=3, stride=1, padding=1, bias=bias)
 
     def invalidate_prepared(self):
-        """Drop the prepared bf16 weights of every block (needed only after parameter writes that bypass torch's
-        version counter, i.e. through ``param.data``)."""
+        """Drop the prepared weights of every block.  Happens by itself on every .train() / .eval() switch, .to() and
+        after a DataParallelTrainer step; call it by hand after parameter writes that bypass torch's version counter
+        (a fused optimiser, ``param.data``) when an evaluation follows WITHOUT such a switch."""
         for m in self.modules():
-            for name in ("_pk_cache", "_f32_cache"):
-                cache = getattr(m, name, None)
-                if cache is not None:
-                    cache.invalidate()
+            if isinstance(m, TransformerBlock):
+                m.invalidate_prepared()
 
     def _apply(self, fn, *args, **kwargs):
         # .to() / .float() / .cuda() may replace parameter storage behind the same version number
@@ -311,7 +323,7 @@ class Restormer(nn.Module):
         upk = up(d1, self.output_upscale)
         if self.dual_pixel_task:
             out = self.output(pk.unpack(upk, torch.float32) + skip)
-        elif self.output.weight.shape[0] <= 4 and not via_torch:
+        elif self.output.weight.shape[0] <= 4 and self.output.weight.shape[0] == inp_img.shape[1] and not via_torch:
             # last layer + bilinear x2 of the input in one kernel that reads the packed tensor: fp32 weights and sums, and
             # the image never passes through a bf16 container on its way out
             out = pk.conv3x3_fewout(upk, self.output.weight, self.output.bias, lowres=inp_img.float())
@@ -335,15 +347,12 @@ class Restormer(nn.Module):
     # each other's gaps: 16 x 3 x 256^2 takes 16.5 instead of 17.6 ms, and halves that do not fill the chip lose
     # (2 x 256^2: 6.2 against 5.3 ms), hence the size bound.  The samples of a batch never meet (attention is per
     # sample), and the result is bit for bit that of the two half-batch calls.
-    # The fp32 path is NOT split: it gained less (35.1 against 36.0 ms), and its results moved (up to 2e-3 at the
-    # headline shape, every run) when kernels of two streams overlapped: in the blocks with 192 / 384 channels the
-    # gated depthwise kernel then produces wrong 4 x 4 strips (its input, project_in's output, is right in memory
-    # afterwards).  The fp32 entry points of the library should not be driven from two streams at once.
-    # Opt-in (model.two_streams = True, or RST_TWO_STREAMS=1 in the environment; RST_TWO_STREAMS=0: never): with two
-    # streams active this platform does not always keep a kernel behind the kernel it depends on -- in fp32 the gated
-    # depthwise kernel at 192 / 384 channels sometimes reads project_in's output before it is there (an event marker
-    # between the two cures most of it) -- and although the bf16 path has been bit-exact in every run so far, that is
-    # an observation, not a guarantee.
+    # Opt-in (model.two_streams = True, or RST_TWO_STREAMS=1 in the environment; RST_TWO_STREAMS=0: never), and never
+    # for fp32: on MI355X a wave that issues v_mfma_f32_16x16x32_{f16,bf16} densely can make a wave of a kernel from
+    # the OTHER stream on the same compute unit lose lanes 48..63 of one instruction of a dependent multiply-add chain
+    # (tools/two_stream_repro.hip shows it without this library).  In fp32 that hit the gated depthwise kernel beside
+    # the other half's attention product in most runs (up to 2e-2); the bf16 path has been bit-exact in every run so
+    # far, which is an observation, not a guarantee.
     two_streams = False
     two_streams_min_pixels = 4 * 256 * 256  # input pixels per half-batch from which the split pays
 

@@ -67,6 +67,32 @@ class Collectives:
                 q.wait()
 
 
+class NullCollectives(Collectives):
+    """The same call pattern with nothing sent: a trainer built on it keeps its buckets, hooks and divisions and skips
+    only the exchange.  For measuring what the collectives of a step cost (bench.py: step time with RCCL minus step
+    time with this)."""
+
+    class _Done:
+        def wait(self):
+            return True
+
+    def __init__(self, world: int = 2):
+        super().__init__(None, eager=True)
+        self._world = world
+
+    def world_size(self) -> int:
+        return self._world
+
+    def all_reduce(self, t, op=None, async_op: bool = False):
+        return self._Done() if async_op else None
+
+    def broadcast(self, t, src: int = 0) -> None:
+        return None
+
+    def exchange(self, pairs) -> None:
+        return None
+
+
 def _comm(comm: Optional[Collectives], process_group) -> Collectives:
     return comm if comm is not None else Collectives(process_group)
 

@@ -22,36 +22,56 @@ def _net(case):
     return net.cuda(), x.cuda(), tgt.cuda()
 
 
+def _kind(name):
+    return ("temperature" if name.endswith("temperature") else "ln" if ".norm" in name else
+            "dw" if "dwconv" in name else "dense")
+
+
 def test_bf16_training_gradients_vs_reference_fixture():
-    """dim 48, 1 x 3 x 32 x 32: loss and every parameter gradient of the bf16-activation path against the fixture written
-    by the reference module in fp64 (norm per tensor; direction through the pinned sub-samples)."""
+    """dim 48, 1 x 3 x 32 x 32: loss and EVERY parameter gradient of the bf16-activation path, tensor by tensor, against
+    the fixture the reference module wrote in fp64 (`model_dim48_rgb_allgrads`: tensors up to 1024 elements in full --
+    every temperature and LayerNorm parameter -- the others as a fixed 1024-element sub-sample, plus every norm).
+    Measured values (MI355X) are quoted beside the bounds; a sign error or a factor of two in any one tensor, however
+    small, fails the cosine / ratio of that tensor."""
     case = recipe.MODEL_CASES[1]
-    g = load("model_" + case[0])
+    g = load("model_" + case[0] + "_allgrads")
     net, x, tgt = _net(case)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         out = net(x)
     assert out.dtype == torch.float32 and out.requires_grad
     loss = (out - tgt).abs().mean()
     loss.backward()
-    assert abs(loss.item() - float(g["loss"])) <= 5e-3 * float(g["loss"])           # measured ~5e-4
-    num = den_a = den_b = 0.0
-    worst_norm = 0.0
+    assert abs(loss.item() - float(g["loss"])) <= 1e-3 * float(g["loss"])           # measured 2.8e-4
+    gn_ref = math.sqrt(sum(float(g["gl2/" + k]) ** 2 for k, _ in net.named_parameters()))
+    worst = {}
     for k, p in net.named_parameters():
         assert p.grad is not None and p.grad.dtype == torch.float32 and torch.isfinite(p.grad).all(), k
-        ref = float(g["gl2/" + k])
-        got = float(p.grad.double().norm())
-        if ref > 1e-3 * float(g["grad_norm"]):                                       # tensors that carry the gradient
-            worst_norm = max(worst_norm, abs(got - ref) / ref)
-        if ("d/" + k + "/v") in g:
-            idx = recipe.subsample_index(p.grad.numel())
-            a = p.grad.detach().double().cpu().numpy().reshape(-1)[idx]
-            b = g["d/" + k + "/v"].astype(np.float64)
-            num += float((a * b).sum()); den_a += float((a * a).sum()); den_b += float((b * b).sum())
-    cos = num / math.sqrt(den_a * den_b)
-    assert cos > 0.995, cos                                                          # measured ~0.9995
-    assert worst_norm < 0.1, worst_norm
+        ref_n, got_n = float(g["gl2/" + k]), float(p.grad.double().norm())
+        share = ref_n / gn_ref
+        idx = recipe.subsample_index(p.grad.numel(), count=1024)
+        a = p.grad.detach().double().cpu().numpy().reshape(-1)[idx]
+        b = g["g/" + k].astype(np.float64)
+        kind = _kind(k)
+        ratio = got_n / ref_n
+        if kind == "temperature":
+            # one to eight numbers per tensor, each a small difference of large sums: sign and size, element by element,
+            # where the element carries weight (measured: ratios 0.62 .. 1.06, the outliers below 1e-4 of the norm)
+            if share > 1e-4:
+                assert np.all(np.sign(a) == np.sign(b)), (k, a, b)
+                assert 0.8 < ratio < 1.2, (k, ratio)                                  # measured 0.96 .. 1.03
+            else:
+                assert 0.4 < ratio < 1.6, (k, ratio)
+            continue
+        cos = float((a * b).sum() / math.sqrt((a * a).sum() * (b * b).sum()))
+        w = worst.setdefault(kind, [1.0, 1.0, 1.0])
+        w[0] = min(w[0], cos); w[1] = min(w[1], ratio); w[2] = max(w[2], ratio)
+        # measured over all 451 tensors: cosine >= 0.9976 (the 192 / 384-channel levels; >= 0.9997 at 48 channels),
+        # norm ratio 0.937 .. 1.038
+        assert cos > (0.997 if share > 1e-3 else 0.99), (k, cos, share)
+        assert 0.9 < ratio < 1.1, (k, ratio)
     gn = math.sqrt(sum(float((p.grad.double() ** 2).sum()) for p in net.parameters()))
-    assert abs(gn - float(g["grad_norm"])) <= 3e-2 * float(g["grad_norm"])
+    assert abs(gn - gn_ref) <= 1e-2 * gn_ref, (gn, gn_ref)                            # measured 3e-3
+    print("worst cosine / ratio range per kind:", worst)
 
 
 def test_bf16_training_trajectory_vs_oracle():
@@ -130,3 +150,28 @@ def test_trainer_steps_leave_no_stale_prepared_weights(autocast):
         net.invalidate_prepared()
         l_want = float((net(x) - tgt).abs().mean().detach())
     assert abs(l_got - l_want) <= 1e-5 * abs(l_want)
+
+
+@pytest.mark.parametrize("autocast", [False, True])
+def test_plain_fused_adam_loop_then_eval_sees_the_new_weights(autocast):
+    """A training loop that is not the library's trainer (torch's fused Adam: parameters change without their version
+    counters moving), then model.eval() and a no_grad forward, as validate() / test_psnr do: the evaluation has to run
+    on the updated weights.  The mode switch drops the prepared weights."""
+    net, x, tgt = _net(recipe.MODEL_CASES[1])
+    net.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        before = net(x).float()                                   # fills the inference caches with the initial weights
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
+    for _ in range(2):
+        opt.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            (net(x).float() - tgt).abs().mean().backward()
+        opt.step()
+    net.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        got = net(x).float()
+        net.invalidate_prepared()
+        want = net(x).float()
+    assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    assert float((got - before).abs().max()) > 1e-2 * float(want.abs().max())     # the steps did change the output

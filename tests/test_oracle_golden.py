@@ -90,3 +90,21 @@ def test_elementary_maps():
     assert torch.allclose(orc.bilinear_up2(x), up, atol=1e-13)
     assert torch.allclose(orc.gelu_erf(x), torch.nn.functional.gelu(x), atol=1e-14)
     assert orc.psnr(x, x) == float("inf")
+
+
+def test_oracle_gradients_match_every_tensor_of_the_allgrads_fixture():
+    """The oracle's fp64 autograd against `model_dim48_rgb_allgrads` (every parameter tensor of the dim-48 network,
+    written by the reference module): the fixture the bf16 training test leans on."""
+    import numpy as np
+    case = recipe.MODEL_CASES[1]
+    g = load("model_" + case[0] + "_allgrads")
+    sd, x, tgt = recipe.model_case_tensors(case, torch.float64)
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    loss = (orc.restormer_forward(x, sd) - tgt).abs().mean()
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-12
+    for k, v in sd.items():
+        a = v.grad.numpy().reshape(-1)[recipe.subsample_index(v.numel(), count=1024)]
+        b = g["g/" + k].astype(np.float64)
+        assert np.abs(a - b).max() <= 2e-7 * max(np.abs(b).max(), 1e-30) + 1e-12, k         # the fixture is stored as fp32
+        assert abs(float(np.sqrt((v.grad ** 2).sum())) - float(g["gl2/" + k])) <= 1e-9 * float(g["gl2/" + k]) + 1e-15, k

@@ -187,3 +187,22 @@ def test_halo_rows_come_from_the_neighbours(world, tmp_path):
     out = str(tmp_path / "halo.pt")
     spawn_bounded(_halo_worker, (world, _free_port(), out), world)
     assert torch.load(out) == [1.0] * world
+
+
+def test_null_collectives_keep_the_bucket_path_and_send_nothing():
+    """bench.py measures the exchange of a training step as (step with RCCL) - (step with NullCollectives): the
+    trainer then runs its buckets, hooks, division and clipping exactly as with real peers.  With a world of one the
+    numbers must be those of the plain single-process trainer."""
+    from superresolution_amd.parallel import NullCollectives
+    torch.manual_seed(2)
+    a, b = _TinySR(), _TinySR()
+    b.load_state_dict(a.state_dict())
+    x, t = torch.rand(2, 3, 8, 8), torch.rand(2, 3, 16, 16)
+    ta = DataParallelTrainer(a, world_size=1, comm=NullCollectives(), bucket_mb=0.001)
+    assert ta.reduce and len(ta.buckets) > 1
+    tb = DataParallelTrainer(b, world_size=1)
+    for _ in range(3):
+        la, lb = ta.step(x, t), tb.step(x, t)
+        assert abs(la.item() - lb.item()) < 1e-7
+    for (k, p), q in zip(a.state_dict().items(), b.state_dict().values()):
+        assert torch.allclose(p, q, atol=1e-7), k
