@@ -406,6 +406,39 @@ size_t rst_bf16_block_bwd_workspace_bytes(const rst_block_desc* desc);
 int rst_bf16_block_bwd(const rst_block_desc* desc, const rst_block_params* params, const void* prepared,
                        const void* x_packed, const void* dy_packed, void* dx_packed,
                        rst_block_grads* grads, void* workspace, size_t workspace_bytes, void* stream);
+/* What autograd derives from the glue between the stages when the network trains  */
+/* on bf16 tensors (model/Restromer.py:172-215, 381-383: OverlapPatchEmbed,        */
+/* Downsample, Upsample, the output convolution; :309-311, 326-328: the 1x1         */
+/* reductions; :402, 407, 412: torch.cat; nn.PixelShuffle / nn.PixelUnshuffle):     */
+/* rst_bf16_conv3x3_bwd: from the packed input x of rst_bf16_conv3x3_fwd and the    */
+/* packed gradient dy of its (shuffled) output: dx (packed; NULL: not wanted -- the  */
+/* first layer; otherwise Cin % 8 == 0), dweight [Cout][Cin][3][3] and dbias [Cout]  */
+/* (NULL: none) in fp32, overwritten.  shuffle_mode 0 also takes Cout < 8 (the last  */
+/* layer, whose forward is rst_bf16_conv3x3_fewout_fwd; dy then holds Cout channels  */
+/* in one block).  workspace_bytes query returns 0 for unsupported shapes.           */
+size_t rst_bf16_conv3x3_bwd_workspace_bytes(int32_t B, int32_t Cin, int32_t Cout, int32_t H, int32_t W,
+                                            int32_t shuffle_mode, int32_t want_dx);
+int rst_bf16_conv3x3_bwd(const void* x_packed, const void* dy_packed, const float* weight, void* dx_packed,
+                         float* dweight, float* dbias, int32_t B, int32_t Cin, int32_t Cout, int32_t H, int32_t W,
+                         int32_t shuffle_mode, void* workspace, size_t workspace_bytes, void* stream);
+/* rst_bf16_conv1x1_bwd: gradients of rst_bf16_conv1x1_fwd (without residual): dx    */
+/* packed, dweight [Cout][Cin], dbias [Cout] or NULL.                                */
+size_t rst_bf16_conv1x1_bwd_workspace_bytes(int32_t B, int32_t Cin, int32_t Cout, int64_t N);
+int rst_bf16_conv1x1_bwd(const void* x_packed, const void* dy_packed, const float* weight, void* dx_packed,
+                         float* dweight, float* dbias, int32_t B, int32_t Cin, int32_t Cout, int64_t N,
+                         void* workspace, size_t workspace_bytes, void* stream);
+/* nn.PixelShuffle(2): [B][4 C_out][H_in][W_in] -> [B][C_out][2 H_in][2 W_in], and    */
+/* nn.PixelUnshuffle(2): [B][C_in][H_in][W_in] -> [B][4 C_in][H_in/2][W_in/2], packed   */
+/* in and out (each is the other's gradient); C_out / C_in multiples of 8.           */
+int rst_bf16_pixel_shuffle2(const void* x_packed, void* y_packed, int32_t B, int32_t C_out, int32_t H_in, int32_t W_in,
+                            void* stream);
+int rst_bf16_pixel_unshuffle2(const void* x_packed, void* y_packed, int32_t B, int32_t C_in, int32_t H_in, int32_t W_in,
+                              void* stream);
+/* torch.cat along the channels and its gradient, one half at a time: channels        */
+/* [src_c0, src_c0 + nC) of src (src_C channels) into [dst_c0, dst_c0 + nC) of dst    */
+/* (dst_C channels); everything in whole blocks of 8.                                 */
+int rst_bf16_copy_channel_blocks(const void* src_packed, int32_t src_C, int32_t src_c0, void* dst_packed, int32_t dst_C,
+                                 int32_t dst_c0, int32_t nC, int32_t B, int64_t N, void* stream);
 /* The same pair for a training step that can spare a little memory per block     */
 /* (what autograd keeps of model/Restromer.py:141-146 -- attn before and after      */
 /* the softmax -- plus the norms of q and k and the product with project_out):      */

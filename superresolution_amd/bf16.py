@@ -252,7 +252,10 @@ class _StageFn(torch.autograd.Function):
         if not x.is_cuda or x.dtype != torch.bfloat16:
             raise RuntimeError("bf16 stage: expected a bf16 tensor on a ROCm GPU")
         import os
-        p = pack(x)
+        # a 5-D tensor is the packed layout itself (B, C/8, H, W, 8): the training network hands its stages packed
+        # tensors and gets packed tensors back, gradients included
+        ctx.packed_io = x.dim() == 5
+        p = Packed(x.contiguous(), x.shape[1] * 8) if ctx.packed_io else pack(x)
         kept, attn = [], []
         keep_attn = os.environ.get("RST_BF16_KEEP_ATTN", "1") != "0"
         n = len(PARAM_FIELDS)
@@ -264,11 +267,11 @@ class _StageFn(torch.autograd.Function):
             if keep_attn:
                 attn.append(a)
             p = out
-        ctx.metas, ctx.shape, ctx.caches = metas, tuple(x.shape), caches
+        ctx.metas, ctx.shape, ctx.caches = metas, tuple(p.shape), caches
         ctx.present = [t is not None for t in flat]
         ctx.keep_attn = keep_attn
         ctx.save_for_backward(*kept, *attn, *[t for t in flat if t is not None])
-        return unpack(p, torch.bfloat16)
+        return p.data if ctx.packed_io else unpack(p, torch.bfloat16)
 
     @staticmethod
     def backward(ctx, dy):
@@ -283,7 +286,7 @@ class _StageFn(torch.autograd.Function):
         grads = [None] * len(flat)
         if os.environ.get("RST_BF16_BWD", "bf16") == "fp32":
             from . import ops
-            g = dy.float().contiguous()
+            g = (unpack(Packed(dy.contiguous(), C), torch.float32) if ctx.packed_io else dy.float().contiguous())
             for i in reversed(range(nb)):
                 heads, hidden = ctx.metas[i]
                 params = dict(zip(PARAM_FIELDS, flat[i * n:(i + 1) * n]))
@@ -291,15 +294,15 @@ class _StageFn(torch.autograd.Function):
                 g, pg = ops.block_recompute_backward(x32, g, heads, hidden, params)
                 for j, name in enumerate(PARAM_FIELDS):
                     grads[i * n + j] = pg[name]
-            return (g.to(torch.bfloat16), None, None) + tuple(grads)
-        g = pack(dy.contiguous())
+            return ((pack(g).data if ctx.packed_io else g.to(torch.bfloat16)), None, None) + tuple(grads)
+        g = Packed(dy.contiguous(), C) if ctx.packed_io else pack(dy.contiguous())
         for i in reversed(range(nb)):
             heads, hidden = ctx.metas[i]
             params = dict(zip(PARAM_FIELDS, flat[i * n:(i + 1) * n]))
             g, pg = block_backward(Packed(kept[i], C), g, heads, hidden, params, ctx.caches[i], attn[i] if na else None)
             for j, name in enumerate(PARAM_FIELDS):
                 grads[i * n + j] = pg[name]
-        return (unpack(g, torch.bfloat16), None, None) + tuple(grads)
+        return ((g.data if ctx.packed_io else unpack(g, torch.bfloat16)), None, None) + tuple(grads)
 
 
 def block_backward(x: Packed, dy: Packed, heads: int, hidden: int, params: Dict[str, Optional[torch.Tensor]],
@@ -379,3 +382,152 @@ def stage(x: torch.Tensor, blocks) -> torch.Tensor:
         par = b._params()
         flat.extend(par[n] for n in PARAM_FIELDS)
     return _StageFn.apply(x, metas, caches, *flat)
+
+
+# ----------------------------------------------------------------------------
+# the glue between the stages, differentiable, on packed tensors (training)
+# ----------------------------------------------------------------------------
+def _packed_data(t: torch.Tensor, what: str) -> torch.Tensor:
+    if not t.is_cuda or t.dtype != torch.bfloat16 or t.dim() != 5 or t.shape[-1] != 8:
+        raise RuntimeError(f"{what}: expected a packed bf16 tensor (B, C/8, H, W, 8) on a ROCm GPU")
+    return t.contiguous()
+
+
+def conv3x3_backward(x: Packed, dy: Packed, weight: torch.Tensor, mode: int = 0, want_dx: bool = True, want_bias: bool = False):
+    """Gradients of `conv3x3(x, weight, bias, mode)` from the packed gradient `dy` of its (shuffled) output
+    (rst_bf16_conv3x3_bwd): (dx packed or None, dweight fp32, dbias fp32 or None)."""
+    lib = _lib.load()
+    B, Cin, H, W = x.shape
+    w = _f32(weight, "conv3x3 weight")
+    Cout = w.shape[0]
+    if tuple(w.shape) != (Cout, Cin, 3, 3):
+        raise RuntimeError(f"conv3x3 backward: weight {tuple(w.shape)} does not fit {Cin} input channels")
+    Co, Ho, Wo = (Cout, H, W) if mode == 0 else (4 * Cout, H // 2, W // 2) if mode == 1 else (Cout // 4, 2 * H, 2 * W)
+    if dy.shape != (B, Co, Ho, Wo):
+        raise RuntimeError(f"conv3x3 backward: gradient shape {dy.shape} != {(B, Co, Ho, Wo)}")
+    nb = lib.rst_bf16_conv3x3_bwd_workspace_bytes(B, Cin, Cout, H, W, mode, int(want_dx))
+    if nb == 0:
+        raise RuntimeError(f"conv3x3 backward: shape Cin={Cin} Cout={Cout} {H}x{W} mode={mode} not supported")
+    ws = workspace(nb, x.data.device)
+    dx = torch.empty_like(x.data) if want_dx else None
+    dw = torch.empty_like(w)
+    db = torch.empty(Cout, dtype=torch.float32, device=w.device) if want_bias else None
+    check(lib.rst_bf16_conv3x3_bwd(_ptr(x.data), _ptr(dy.data), _ptr(w), _ptr(dx), _ptr(dw), _ptr(db), B, Cin, Cout, H, W, mode,
+                                   _ptr(ws), ws.numel(), _stream()), "rst_bf16_conv3x3_bwd")
+    return (Packed(dx, Cin) if want_dx else None), dw, db
+
+
+class _Conv3x3TrainFn(torch.autograd.Function):
+    """conv3x3 (+ PixelUnshuffle / PixelShuffle) on a packed tensor, differentiable: reference model/Restromer.py:172-215."""
+
+    @staticmethod
+    def forward(ctx, xdata, cin, weight, bias, mode):
+        x = Packed(_packed_data(xdata, "conv3x3"), cin)
+        y = conv3x3(x, weight, bias, mode)
+        ctx.save_for_backward(x.data, weight)
+        ctx.cin, ctx.cout_shuffled, ctx.mode, ctx.has_bias = cin, y.C, mode, bias is not None
+        return y.data
+
+    @staticmethod
+    def backward(ctx, dy):
+        xdata, weight = ctx.saved_tensors
+        dx, dw, db = conv3x3_backward(Packed(xdata, ctx.cin), Packed(dy.contiguous(), ctx.cout_shuffled), weight, ctx.mode,
+                                      ctx.needs_input_grad[0], ctx.has_bias)
+        return (dx.data if dx is not None else None), None, dw.view_as(weight), db, None
+
+
+class _Conv1x1TrainFn(torch.autograd.Function):
+    """nn.Conv2d(kernel_size=1) on a packed tensor, differentiable: the reductions after the skip concatenations
+    (model/Restromer.py:309-311, 326-328, 403, 408)."""
+
+    @staticmethod
+    def forward(ctx, xdata, cin, weight, bias):
+        x = Packed(_packed_data(xdata, "conv1x1"), cin)
+        y = conv1x1(x, weight, bias)
+        ctx.save_for_backward(x.data, weight)
+        ctx.cin, ctx.cout, ctx.has_bias = cin, y.C, bias is not None
+        return y.data
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = _lib.load()
+        xdata, weight = ctx.saved_tensors
+        B, _, H, W, _ = xdata.shape
+        w = _f32(weight, "conv1x1 weight")
+        dy = dy.contiguous()
+        ws = workspace(lib.rst_bf16_conv1x1_bwd_workspace_bytes(B, ctx.cin, ctx.cout, H * W), xdata.device)
+        dx = torch.empty_like(xdata)
+        dw = torch.empty_like(w)
+        db = torch.empty(ctx.cout, dtype=torch.float32, device=w.device) if ctx.has_bias else None
+        check(lib.rst_bf16_conv1x1_bwd(_ptr(xdata), _ptr(dy), _ptr(w), _ptr(dx), _ptr(dw), _ptr(db), B, ctx.cin, ctx.cout, H * W,
+                                       _ptr(ws), ws.numel(), _stream()), "rst_bf16_conv1x1_bwd")
+        return dx, None, dw.view_as(weight), db
+
+
+def _copy_blocks(src, src_c0, dst, dst_c0, nc):
+    lib = _lib.load()
+    B, scb, H, W, _ = src.shape
+    check(lib.rst_bf16_copy_channel_blocks(_ptr(src), scb * 8, src_c0, _ptr(dst), dst.shape[1] * 8, dst_c0, nc, B, H * W, _stream()),
+          "rst_bf16_copy_channel_blocks")
+
+
+class _CatTrainFn(torch.autograd.Function):
+    """torch.cat([a, b], 1) of two packed tensors (model/Restromer.py:402, 407, 412) and its gradient, whole channel
+    blocks copied by the library."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _packed_data(a, "cat"), _packed_data(b, "cat")
+        if a.shape[0] != b.shape[0] or a.shape[2:] != b.shape[2:]:
+            raise RuntimeError(f"cat: shapes {tuple(a.shape)} and {tuple(b.shape)} do not go together")
+        out = torch.empty((a.shape[0], a.shape[1] + b.shape[1]) + tuple(a.shape[2:]), dtype=a.dtype, device=a.device)
+        _copy_blocks(a, 0, out, 0, a.shape[1] * 8)
+        _copy_blocks(b, 0, out, a.shape[1] * 8, b.shape[1] * 8)
+        ctx.ca, ctx.cb = a.shape[1], b.shape[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        B, _, H, W, _ = dy.shape
+        da = torch.empty((B, ctx.ca, H, W, 8), dtype=dy.dtype, device=dy.device)
+        db = torch.empty((B, ctx.cb, H, W, 8), dtype=dy.dtype, device=dy.device)
+        _copy_blocks(dy, 0, da, 0, ctx.ca * 8)
+        _copy_blocks(dy, ctx.ca * 8, db, 0, ctx.cb * 8)
+        return da, db
+
+
+class _FewOutTrainFn(torch.autograd.Function):
+    """The last layer on a packed tensor plus the bilinear x2 of the network input (model/Restromer.py:381-383, 420-431),
+    fp32 result; backward: the fp32 output gradient goes into the packed bf16 layout (3 channels in one block) and
+    through the same 3x3 backward as every other convolution."""
+
+    @staticmethod
+    def forward(ctx, xdata, cin, weight, bias, lowres):
+        x = Packed(_packed_data(xdata, "last layer"), cin)
+        ctx.save_for_backward(x.data, weight)
+        ctx.cin, ctx.has_bias = cin, bias is not None
+        return conv3x3_fewout(x, weight, bias, lowres=lowres)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xdata, weight = ctx.saved_tensors
+        dx, dw, db = conv3x3_backward(Packed(xdata, ctx.cin), pack(dy.float().contiguous()), weight, 0, ctx.needs_input_grad[0],
+                                      ctx.has_bias)
+        return (dx.data if dx is not None else None), None, dw.view_as(weight), db, None
+
+
+def conv3x3_train(xdata, cin, conv, mode=0):
+    return _Conv3x3TrainFn.apply(xdata, cin, conv.weight, conv.bias, mode)
+
+
+def conv1x1_train(xdata, cin, conv):
+    return _Conv1x1TrainFn.apply(xdata, cin, conv.weight, conv.bias)
+
+
+def cat_train(a, b):
+    return _CatTrainFn.apply(a, b)
+
+
+def fewout_train(xdata, cin, conv, lowres):
+    return _FewOutTrainFn.apply(xdata, cin, conv.weight, conv.bias, lowres)

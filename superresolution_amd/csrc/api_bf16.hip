@@ -404,6 +404,21 @@ int pk_wgrad(const bf16_t* a, int64_t a_bs, int Ab, const bf16_t* bm, int64_t b_
     return reduce_slabs_launch(part, out, rec, per_sample ? B : 1, per_sample ? g.splits : B * g.splits, 0, stream);
 }
 
+// ---- 1x1 convolution on packed tensors, backward (the reductions after a skip concatenation) ----
+struct Conv1BwdBufs {
+    PkSliced wT;
+    float *part, *red;
+    size_t part_floats;
+};
+void conv1_bwd_carve(int B, int Cin, int Cout, int64_t N, Carve& cv, Conv1BwdBufs& b) {
+    const int Cip = pad8(Cin), Cop = pad8(Cout);
+    b.wT = pk_sliced_shape(Cip, Cop);
+    pk_sliced_carve(b.wT, cv, 1);
+    b.part_floats = wgrad_pk_partial_floats(pk_wgrad_shape(Cop / 8, Cip / 8, B, N, true));
+    b.part = cv.floats(b.part_floats);
+    b.red = cv.floats((size_t)Cop * Cip + Cop);
+}
+
 // The backward pass of a block is two kinds of work: the chain of data gradients (each kernel waits for the one before
 // it) and the parameter gradients (products over the pixels, slab sums, small rearrangements), which only READ what
 // the chain leaves behind.  At training sizes most of these kernels fill a fraction of the chip, so with
@@ -743,6 +758,46 @@ int rst_bf16_conv1x1_fwd(const void* x_packed, const float* weight, const float*
     g.R = static_cast<const bf16_t*>(residual_packed); g.r_bs = ys;
     g.ln_c = bias ? w.c : nullptr;
     return gemm_pk_launch(g, st);
+}
+
+size_t rst_bf16_conv1x1_bwd_workspace_bytes(int32_t B, int32_t Cin, int32_t Cout, int64_t N) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || N <= 0) return 0;
+    Carve cv(nullptr); Conv1BwdBufs b{};
+    conv1_bwd_carve(B, Cin, Cout, N, cv, b);
+    return cv.total();
+}
+int rst_bf16_conv1x1_bwd(const void* x_packed, const void* dy_packed, const float* weight, void* dx_packed, float* dweight,
+                         float* dbias, int32_t B, int32_t Cin, int32_t Cout, int64_t N, void* workspace, size_t workspace_bytes,
+                         void* stream) {
+    RST_REQUIRE(x_packed && dy_packed && weight && dx_packed && dweight, "bf16 conv1x1 backward: null operand");
+    RST_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && N > 0, "bf16 conv1x1 backward: empty shape");
+    RST_REQUIRE(aligned16(x_packed) && aligned16(dy_packed) && aligned16(dx_packed), "bf16 conv1x1 backward: tensors must be 16-byte aligned");
+    if (workspace == nullptr || !aligned16(workspace) || workspace_bytes < rst_bf16_conv1x1_bwd_workspace_bytes(B, Cin, Cout, N))
+        return fail(RST_ERR_WORKSPACE, "bf16 conv1x1 backward: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bf16_t* x = static_cast<const bf16_t*>(x_packed);
+    const bf16_t* dy = static_cast<const bf16_t*>(dy_packed);
+    Carve cv(workspace); Conv1BwdBufs b{};
+    conv1_bwd_carve(B, Cin, Cout, N, cv, b);
+    const int Cip = pad8(Cin), Cop = pad8(Cout);
+    // dx = W^T dy: fragments of the transposed weights, the contraction over the output channels in slices of 480
+    {
+        PrepAtJobs jobs{};
+        RST_REQUIRE(b.wT.nslices <= 8, "bf16 conv1x1 backward: too many slices");
+        for (int i = 0; i < b.wT.nslices; ++i) {
+            PrepAtJob& q = jobs.job[jobs.n++];
+            q.w = weight; q.ldw = Cin; q.transA = 1; q.M = Cin; q.mseg = NOSEG; q.mseg_pad = NOSEG;
+            q.Ksrc = Cout; q.kseg = NOSEG; q.kseg_pad = NOSEG; q.kpos0 = b.wT.kpos0[i]; q.Krange = b.wT.krange[i];
+            q.ntiles = b.wT.w[i].ntiles; q.KS = b.wT.w[i].KS; q.frag = b.wT.w[i].frag;
+        }
+        RST_TRY(pk_prep_at_jobs_launch(jobs, st));
+    }
+    RST_TRY(pk_sliced_gemm(b.wT, dy, (int64_t)Cop * N, static_cast<bf16_t*>(dx_packed), (int64_t)Cip * N, B, N, 0, st));
+    // dW = sum over samples and pixels of dy x^T, db = the sums of dy's rows
+    RST_TRY(pk_wgrad(dy, (int64_t)Cop * N, Cop / 8, x, (int64_t)Cip * N, Cip / 8, B, N, false, true, b.red, b.part, b.part_floats, st));
+    RST_TRY(crop2d_launch(b.red, Cip, dweight, Cout, Cin, st));
+    if (dbias != nullptr) RST_HIP(hipMemcpyAsync(dbias, b.red + (size_t)Cop * Cip, sizeof(float) * Cout, hipMemcpyDeviceToDevice, st));
+    return RST_OK;
 }
 
 size_t rst_bf16_block_workspace_bytes(const rst_block_desc* d) { return check_pk_desc(d) == RST_OK ? pk_block_ws_bytes(d) : 0; }

@@ -128,6 +128,17 @@ wgrad_pk_kernel(const WgradPk g) {
     const bf16x8 ones = __builtin_bit_cast(bf16x8, one8);
 
     u32x4 ra[T], rb[T];
+    // where this lane's chunks of B start: channel block b0 + cbl, or (dense 3x3 taps) a shifted view of a real block
+    int64_t boff[T];
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+        const int cbl = (i * 64 + lane) >> 5;
+        boff[i] = (int64_t)cbl * N;
+        if (g.tap_wp > 0) {
+            const int v = b0 + cbl, tap = v / g.tap_cb, cb = v % g.tap_cb;
+            boff[i] = (int64_t)(cb - b0) * N + (int64_t)(tap / 3 - 1) * g.tap_wp + (tap % 3 - 1);
+        }
+    }
     auto gload = [&](int64_t n0) {
 #pragma unroll
         for (int i = 0; i < T; ++i) {
@@ -135,7 +146,7 @@ wgrad_pk_kernel(const WgradPk g) {
             const int64_t px = n0 + (idx & 31);
             const u32x4 z = {0u, 0u, 0u, 0u};
             ra[i] = (px < p1 && cbl < an) ? Ap[(int64_t)cbl * N + px] : z;
-            rb[i] = (px < p1 && cbl < bn) ? Bp[(int64_t)cbl * N + px] : z;
+            rb[i] = (px < p1 && cbl < bn) ? Bp[boff[i] + px] : z;
         }
     };
     gload(p0);

@@ -38,7 +38,7 @@ struct Conv3Pk {
 
 // frag[mt][q = (dyi * kch + kc) * 3 + dxi][lane] x 16 B: row = permuted position of (mt, lane & 15), k = 32 kc + 8 (lane >> 4) + j
 __global__ void __launch_bounds__(64)
-conv3x3_pk_prep_kernel(const float* __restrict__ w, int Cout, int Cin, int kch, u32x4* __restrict__ frag) {
+conv3x3_pk_prep_kernel(const float* __restrict__ w, int Cout, int Cin, int kch, u32x4* __restrict__ frag, int transposed) {
     const int lane = threadIdx.x, rr = lane & 15, g = lane >> 4;
     const int mt = blockIdx.x, q = blockIdx.y;
     const int dxi = q % 3, kc = (q / 3) % kch, dyi = q / (3 * kch);
@@ -47,7 +47,11 @@ conv3x3_pk_prep_kernel(const float* __restrict__ w, int Cout, int Cin, int kch, 
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int ci = 32 * kc + 8 * g + j;
-        v[j] = (m < Cout && ci < Cin) ? w[(((int64_t)m * Cin + ci) * 3 + dyi) * 3 + dxi] : 0.f;
+        // transposed: the convolution that gives the DATA gradient of y = conv(x, w), w stored [Cin][Cout][3][3] as seen
+        // from here: rows and channels swapped, taps rotated by 180 degrees
+        v[j] = !(m < Cout && ci < Cin) ? 0.f
+             : transposed ? w[(((int64_t)ci * Cout + m) * 3 + (2 - dyi)) * 3 + (2 - dxi)]
+                          : w[(((int64_t)m * Cin + ci) * 3 + dyi) * 3 + dxi];
     }
     frag[((int64_t)mt * gridDim.y + q) * 64 + lane] = pack8(v);
 }
@@ -302,7 +306,7 @@ size_t conv3x3_pk_ws_bytes(int Cin, int Cout) {
 }
 
 int conv3x3_pk_launch(const bf16_t* x, const float* w, const float* bias, bf16_t* y, int B, int Cin, int Cout, int H, int W,
-                      int mode, void* ws, size_t ws_bytes, hipStream_t stream) {
+                      int mode, void* ws, size_t ws_bytes, hipStream_t stream, int transposed) {
     RST_REQUIRE(x && w && y && B > 0 && B <= 65535, "bf16 conv3x3: bad operand");
     RST_REQUIRE(conv3x3_pk_supported(Cin, Cout, H, W, mode),
                 "bf16 conv3x3: unsupported shape Cin=%d Cout=%d H=%d W=%d mode=%d (unshuffle: even H, W, Cout; shuffle: Cout %% 32 == 0; plain: Cout %% 8 == 0)",
@@ -328,7 +332,7 @@ int conv3x3_pk_launch(const bf16_t* x, const float* w, const float* bias, bf16_t
     a.mtiles = a.mblocks * 2 * rt;                            // whole blocks: the fragment buffer covers the padding rows
     a.tiles_x = (int)cdiv(W, a.TW); a.tiles_y = (int)cdiv(H, a.TH);
     hipLaunchKernelGGL(conv3x3_pk_prep_kernel, dim3((unsigned)a.mtiles, (unsigned)(9 * a.kch)), dim3(64), 0, stream, w, Cout, Cin,
-                       a.kch, static_cast<u32x4*>(ws));
+                       a.kch, static_cast<u32x4*>(ws), transposed);
     RST_LAUNCH_CHECK();
     const int64_t gx = (int64_t)a.tiles_x * a.tiles_y * a.mblocks;
     a.walk = xcd_walk_enabled();
@@ -360,6 +364,6 @@ int rst_bf16_conv3x3_fwd(const void* x_packed, const float* weight, const float*
                          int32_t Cout, int32_t H, int32_t W, int32_t shuffle_mode, void* workspace, size_t workspace_bytes,
                          void* stream) {
     return rst::conv3x3_pk_launch(static_cast<const rst::bf16_t*>(x_packed), weight, bias, static_cast<rst::bf16_t*>(y_packed), B, Cin,
-                                  Cout, H, W, shuffle_mode, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+                                  Cout, H, W, shuffle_mode, workspace, workspace_bytes, static_cast<hipStream_t>(stream), 0);
 }
 }

@@ -272,6 +272,10 @@ struct WgradPk {
     int B; int64_t N;
     float* partial; int with_rowsum;
     int T, nsa, nsb, splits; int64_t chunk_px;
+    // taps of a dense 3x3 (tap_wp > 0): Bb counts 9 x tap_cb VIRTUAL channel blocks; virtual block v is channel block
+    // v % tap_cb of Bm read (v / tap_cb / 3 - 1) rows of tap_wp pixels and (v / tap_cb % 3 - 1) pixels further on.
+    // Both tensors are zero-padded images of tap_wp pixels per row (the shifted reads stay inside Bm's margins).
+    int tap_wp, tap_cb;
 };
 void wgrad_pk_plan(WgradPk* g);
 size_t wgrad_pk_partial_floats(const WgradPk& g);
@@ -302,8 +306,17 @@ int attn_bwd_mats_launch(const float* Eq, const float* Dq, const float* Dk, floa
 // ---- conv3x3_pk.hip: dense 3x3 convolution on packed tensors; mode 1 / 2: PixelUnshuffle(2) / PixelShuffle(2) epilogue ----
 bool conv3x3_pk_supported(int Cin, int Cout, int H, int W, int mode);
 size_t conv3x3_pk_ws_bytes(int Cin, int Cout);
+// transposed: w is read as the weights of the convolution that gives the data gradient (rows and channels swapped, taps rotated)
 int conv3x3_pk_launch(const bf16_t* x, const float* w, const float* bias, bf16_t* y, int B, int Cin, int Cout, int H, int W,
-                      int mode, void* ws, size_t ws_bytes, hipStream_t stream);
+                      int mode, void* ws, size_t ws_bytes, hipStream_t stream, int transposed = 0);
+// ---- conv3x3_bwd_pk.hip ----
+bool conv3x3_pk_bwd_supported(int Cin, int Cout, int H, int W, int mode, bool want_dx);
+size_t conv3x3_pk_bwd_ws_bytes(int B, int Cin, int Cout, int H, int W, int mode, int want_dx);
+int conv3x3_pk_bwd_launch(const bf16_t* x, const bf16_t* dy, const float* w, bf16_t* dx, float* dweight, float* dbias, int B, int Cin,
+                          int Cout, int H, int W, int mode, void* ws, size_t ws_bytes, hipStream_t stream);
+int pk_shuffle2_launch(const bf16_t* src, bf16_t* dst, int B, int Cb_big, int h, int w, int to_big, hipStream_t stream);
+int pk_copy_blocks_launch(const bf16_t* src, int src_cb_total, int src_cb0, bf16_t* dst, int dst_cb_total, int dst_cb0, int ncb,
+                          int B, int64_t N, hipStream_t stream);
 
 int pk_to_nhwc_launch(const bf16_t* src, bf16_t* dst, int B, int C, int64_t N, hipStream_t stream);
 int pk_from_nhwc_launch(const bf16_t* src, bf16_t* dst, int mode, int B, int C, int H, int W, hipStream_t stream);

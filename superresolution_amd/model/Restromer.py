@@ -14,6 +14,8 @@ from __future__ import annotations
 
 import numbers
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -410,11 +412,36 @@ class Restormer(nn.Module):
 
     def _forward_bf16_train(self, inp_img):
         """Differentiable forward with bf16 activations (BASELINE config 3: bf16 storage, fp32 sums, fp32 master
-        parameters and gradients).  Every stage of TransformerBlocks is one autograd node that runs the packed bf16
-        kernels forward, keeps only each block's bf16 input, and recomputes the block in fp32 for its backward
-        (`bf16.stage`); the dense 3x3 convolutions, concatenations, pixel (un)shuffles and the 1x1 reductions between
-        the stages are torch operators on bf16 NCHW tensors (their autograd); the last layer and the bilinear residual
-        run in fp32.  Returns the input's dtype."""
+        parameters and gradients), on the library's packed tensors from the first layer to the last: every stage of
+        TransformerBlocks is one autograd node that runs the packed bf16 kernels forward, keeps only each block's bf16
+        input and evaluates the block again for its backward (`bf16.stage`); the dense 3x3 convolutions with their
+        pixel (un)shuffles, the skip concatenations and the 1x1 reductions between the stages are the library's
+        kernels in both directions (`bf16.conv3x3_train`, `cat_train`, `conv1x1_train`); the last layer adds the
+        bilinear x2 of the input inside its kernel and returns fp32.  Returns the input's dtype."""
+        from .. import bf16 as pk
+        if os.environ.get("RST_BF16_TRAIN_GLUE") == "torch" or self.dual_pixel_task or self.output.weight.shape[0] > 4 \
+                or self.output.weight.shape[0] != inp_img.shape[1]:
+            return self._forward_bf16_train_torch_glue(inp_img)
+        dim = self.patch_embed.proj.out_channels
+        with torch.autocast("cuda", enabled=False):
+            x = pk.pack(inp_img.detach().float()).data          # the image needs no gradient
+            e1 = pk.stage(pk.conv3x3_train(x, inp_img.shape[1], self.patch_embed.proj, 0), self.encoder_level1)
+            e2 = pk.stage(pk.conv3x3_train(e1, dim, self.down1_2.body[0], 1), self.encoder_level2)
+            e3 = pk.stage(pk.conv3x3_train(e2, 2 * dim, self.down2_3.body[0], 1), self.encoder_level3)
+            lat = pk.stage(pk.conv3x3_train(e3, 4 * dim, self.down3_4.body[0], 1), self.latent)
+            d3 = pk.cat_train(pk.conv3x3_train(lat, 8 * dim, self.up4_3.body[0], 2), e3)
+            d3 = pk.stage(pk.conv1x1_train(d3, 8 * dim, self.reduce_chan_level3), self.decoder_level3)
+            d2 = pk.cat_train(pk.conv3x3_train(d3, 4 * dim, self.up3_2.body[0], 2), e2)
+            d2 = pk.stage(pk.conv1x1_train(d2, 4 * dim, self.reduce_chan_level2), self.decoder_level2)
+            d1 = pk.cat_train(pk.conv3x3_train(d2, 2 * dim, self.up2_1.body[0], 2), e1)
+            d1 = pk.stage(pk.stage(d1, self.decoder_level1), self.refinement)
+            up = pk.conv3x3_train(d1, 2 * dim, self.output_upscale.body[0], 2)
+            out = pk.fewout_train(up, dim, self.output, inp_img.detach().float())
+        return out.to(inp_img.dtype)
+
+    def _forward_bf16_train_torch_glue(self, inp_img):
+        """The same network with the glue between the stages on torch's bf16 operators and their autograd (A/B aid,
+        RST_BF16_TRAIN_GLUE=torch; also what serves dual_pixel_task and output widths the last-layer kernel does not)."""
         from .. import bf16 as pk
         bf = torch.bfloat16
         with torch.autocast("cuda", enabled=False):

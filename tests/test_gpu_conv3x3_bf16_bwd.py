@@ -1,0 +1,142 @@
+"""Backward of the glue between the stages on packed bf16 tensors (rst_bf16_conv3x3_bwd, rst_bf16_conv1x1_bwd,
+rst_bf16_pixel_(un)shuffle2, rst_bf16_copy_channel_blocks) against the fp64 oracle's autograd -- the gradients of
+OverlapPatchEmbed / Downsample / Upsample / the output convolution / the 1x1 reductions / torch.cat of the reference
+(model/Restromer.py:172-215, 309-311, 381-383, 402) -- on the same bf16-rounded x and dy.
+What is left: the weight gradient is exact bf16 products summed in fp32 (1e-5); the data gradient multiplies
+bf16-rounded weights (the reference rounds them the same way under autocast) and is rounded to bf16 once (2^-9)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _shuffled(y, mode):
+    from oracle import restormer_oracle as orc
+    return {0: lambda t: t, 1: orc.pixel_unshuffle2, 2: orc.pixel_shuffle2}[mode](y)
+
+
+CASES = [  # B, Cin, Cout, H, W, mode, bias, want_dx   (the shapes of tests/test_gpu_conv3x3_bf16.py that a backward can take)
+    (2, 3, 48, 8, 128, 0, False, False), (1, 3, 48, 5, 256, 0, True, False), (2, 48, 24, 6, 128, 1, False, True),
+    (1, 96, 48, 4, 64, 1, False, True), (1, 192, 96, 8, 32, 1, False, True), (1, 384, 768, 4, 32, 2, False, True),
+    (1, 192, 384, 4, 64, 2, False, True), (2, 96, 192, 2, 128, 2, False, True), (1, 96, 192, 3, 256, 2, False, True),
+    (1, 48, 40, 5, 384, 0, True, True), (1, 72, 136, 2, 64, 0, False, True), (1, 96, 192, 7, 480, 2, False, True),
+    (1, 48, 24, 6, 480, 1, True, True), (1, 192, 96, 10, 16, 1, False, True), (1, 8, 16, 9, 40, 0, True, True),
+    (2, 384, 768, 4, 4, 2, False, True), (1, 192, 96, 8, 8, 1, False, True), (2, 48, 3, 12, 40, 0, True, True),
+    (8, 96, 192, 16, 16, 2, False, True),
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,mode,bias,want_dx", CASES)
+def test_conv3x3_bf16_backward_vs_oracle(B, Cin, Cout, H, W, mode, bias, want_dx):
+    from oracle import restormer_oracle as orc
+    from superresolution_amd import bf16
+    g = torch.Generator().manual_seed(B * 1000 + Cin + Cout + H + W + mode)
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16()
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)
+    x64 = x.double().requires_grad_(True)
+    wq = w.bfloat16().double().requires_grad_(True)          # the weights the data gradient is multiplied with
+    w64 = w.double().requires_grad_(True)
+    b64 = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    y = _shuffled(orc.conv3x3(x64, wq, b64), mode)
+    dy = torch.randn(y.shape, generator=g).bfloat16()
+    dx_ref, = torch.autograd.grad(y, x64, dy.double(), retain_graph=True)
+    y2 = _shuffled(orc.conv3x3(x64, w64, b64), mode)
+    dw_ref, db_ref = torch.autograd.grad(y2, (w64, b64), dy.double())
+    dx, dw, db = bf16.conv3x3_backward(bf16.pack(x.cuda()), bf16.pack(dy.cuda()), w.cuda(), mode, want_dx, bias)
+    assert dw.dtype == torch.float32 and tuple(dw.shape) == (Cout, Cin, 3, 3)
+    e_w = float((dw.double().cpu() - dw_ref).abs().max() / dw_ref.abs().max())
+    assert e_w < 2e-5, e_w                                   # measured ~1e-6: fp32 sums of exact products
+    if bias:
+        e_b = float((db.double().cpu() - db_ref).abs().max() / db_ref.abs().max())
+        assert e_b < 2e-5, e_b
+    else:
+        assert db is None
+    if want_dx:
+        got = bf16.unpack(dx, torch.float32).double().cpu()
+        e_x = float((got - dx_ref).abs().max() / dx_ref.abs().max())
+        assert e_x < 6e-3, e_x                               # half a bf16 unit of the largest values
+    else:
+        assert dx is None
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 8, 4, 6), (1, 24, 6, 10), (2, 96, 8, 16), (1, 48, 3, 6)])
+def test_pixel_shuffles_packed_are_torchs(B, C, H, W):
+    """rst_bf16_pixel_shuffle2 / _unshuffle2 against nn.PixelShuffle / nn.PixelUnshuffle, bit for bit, and each undoes
+    the other."""
+    import ctypes
+    from superresolution_amd import _lib, bf16
+    from superresolution_amd.ops import _ptr, _stream
+    lib = _lib.load()
+    x = torch.randn(B, 4 * C, H, W, generator=torch.Generator().manual_seed(C + H)).bfloat16().cuda()
+    p = bf16.pack(x)
+    out = torch.empty((B, C // 8, 2 * H, 2 * W, 8), dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.rst_bf16_pixel_shuffle2(_ptr(p.data), _ptr(out), B, C, H, W, _stream()), "rst_bf16_pixel_shuffle2")
+    got = bf16.unpack(bf16.Packed(out, C))
+    assert torch.equal(got, torch.nn.functional.pixel_shuffle(x, 2))
+    back = torch.empty_like(p.data)
+    _lib.check(lib.rst_bf16_pixel_unshuffle2(_ptr(out), _ptr(back), B, C, 2 * H, 2 * W, _stream()), "rst_bf16_pixel_unshuffle2")
+    assert torch.equal(back, p.data)
+    assert torch.equal(bf16.unpack(bf16.Packed(back, 4 * C)), torch.nn.functional.pixel_unshuffle(got, 2))
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,bias", [(2, 384, 192, 8, 8, False), (1, 192, 96, 6, 20, True), (2, 96, 48, 16, 16, False),
+                                                  (1, 384, 192, 4, 6, True)])
+def test_conv1x1_bf16_backward_vs_oracle(B, Cin, Cout, H, W, bias):
+    """The 1x1 reductions after the skip concatenations, differentiable (`bf16.conv1x1_train`): dx, dW, db against fp64
+    autograd on the same rounded tensors; also through a concatenation (`bf16.cat_train`), whose gradient is a split."""
+    from superresolution_amd import bf16
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    a = torch.randn(B, Cin // 2, H, W, generator=g).bfloat16()
+    b = torch.randn(B, Cin // 2, H, W, generator=g).bfloat16()
+    conv = torch.nn.Conv2d(Cin, Cout, 1, bias=bias)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5)
+    dy = torch.randn(B, Cout, H, W, generator=g).bfloat16()
+    a64, b64 = a.double().requires_grad_(True), b.double().requires_grad_(True)
+    wq = conv.weight.detach().bfloat16().double().requires_grad_(True)
+    w64 = conv.weight.detach().double().requires_grad_(True)
+    bias64 = None if not bias else conv.bias.detach().double().requires_grad_(True)
+    x64 = torch.cat([a64, b64], 1)
+    da_ref, db_ref = torch.autograd.grad(torch.nn.functional.conv2d(x64, wq), (a64, b64), dy.double())
+    grads = torch.autograd.grad(torch.nn.functional.conv2d(x64, w64, bias64), (w64,) + ((bias64,) if bias else ()), dy.double())
+    conv = conv.cuda()
+    pa = bf16.pack(a.cuda()).data.requires_grad_(True)
+    pb = bf16.pack(b.cuda()).data.requires_grad_(True)
+    y = bf16.conv1x1_train(bf16.cat_train(pa, pb), Cin, conv)
+    y.backward(bf16.pack(dy.cuda()).data)
+    for got, ref, C in ((pa.grad, da_ref, Cin // 2), (pb.grad, db_ref, Cin // 2)):
+        v = bf16.unpack(bf16.Packed(got, C), torch.float32).double().cpu()
+        assert float((v - ref).abs().max() / ref.abs().max()) < 6e-3
+    assert float((conv.weight.grad.double().cpu() - grads[0]).abs().max() / grads[0].abs().max()) < 2e-5
+    if bias:
+        assert float((conv.bias.grad.double().cpu() - grads[1]).abs().max() / grads[1].abs().max()) < 2e-5
+
+
+def test_bf16_training_forward_has_no_torch_glue():
+    """The bf16 training step of the dim-48 network, forward and backward, with the packed glue against the same step
+    with torch's operators between the stages (RST_BF16_TRAIN_GLUE=torch): same loss to bf16 accuracy, every gradient
+    tensor pointing the same way."""
+    import os
+    from oracle import recipe
+    from superresolution_amd.model.Restromer import Restormer
+    case = recipe.MODEL_CASES[1]
+    sd, x, tgt = recipe.model_case_tensors(case, torch.float32)
+    res = {}
+    for glue in ("hip", "torch"):
+        net = Restormer(**case[1]); net.load_state_dict(sd, strict=True); net = net.cuda()
+        if glue == "torch":
+            os.environ["RST_BF16_TRAIN_GLUE"] = "torch"
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = (net(x.cuda()) - tgt.cuda()).abs().mean()
+            loss.backward()
+        finally:
+            os.environ.pop("RST_BF16_TRAIN_GLUE", None)
+        res[glue] = (float(loss), {k: p.grad.double().cpu() for k, p in net.named_parameters()})
+    assert abs(res["hip"][0] - res["torch"][0]) < 2e-3 * abs(res["torch"][0])
+    for k, gt in res["torch"][1].items():
+        gh = res["hip"][1][k]
+        if float(gt.norm()) < 1e-9:
+            continue
+        cos = float((gh * gt).sum() / (gh.norm() * gt.norm()))
+        assert cos > 0.98, (k, cos)
