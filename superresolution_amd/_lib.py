@@ -114,6 +114,8 @@ SIGNATURES = {
     "rst_bf16_pixel_shuffle2": (c_int32, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
     "rst_bf16_pixel_unshuffle2": (c_int32, [_P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
     "rst_bf16_copy_channel_blocks": (c_int32, [_P, c_int32, c_int32, _P, c_int32, c_int32, c_int32, c_int32, c_int64, _P]),
+    "rst_conv3x3_bwd_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
+    "rst_conv3x3_bwd": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, c_size_t, _P]),
     "rst_raw_prepare": (c_int32, [_P, c_int32, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
     "rst_profile_begin": (c_int32, []),
     "rst_profile_end": (c_int32, [c_char_p, c_size_t]),

@@ -111,6 +111,7 @@ conv3x3_f16s_kernel(Conv3F a) {
                 chrow = 2 * id + (lane >> 5);
                 const int n = (lane & 31) * 4;
                 ys = y0 + n / TW + dy; xs = x0 + n % TW;
+                if (xs > W - 4) xs = W - 4;                           // right of the image (last tile of a row): zeroed when converted
                 dst = st + id * C3_XPIECE;
             } else {
                 chrow = lane >> 1;
@@ -172,7 +173,7 @@ conv3x3_f16s_kernel(Conv3F a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { v[2 * j] = xs[4 * j * C3_XPIECE]; v[2 * j + 1] = xs[4 * j * C3_XPIECE + 128]; }
             const int yy = y0 + cty + dy;
-            split_store(v, yy >= 0 && yy < H, im, cslot, cg);
+            split_store(v, yy >= 0 && yy < H && x0 + ctx < W, im, cslot, cg);
         }
         if (TW == 128 && wave == 0 && lane < 8) {
             // the two columns either side of a full-width tile (one tile row): halo piece [channel][side][4 px]
@@ -274,7 +275,7 @@ conv3x3_f16s_kernel(Conv3F a) {
             for (int h = 0; h < 2; ++h) {
                 const int row = rr + 8 * h, m = mbase + row;
                 const f32x4 v = *reinterpret_cast<const f32x4*>(&sl[row * C3_SCR_LD + c4]);
-                if (m < a.Cout) *reinterpret_cast<f32x4*>(Yb + (int64_t)m * HW + (int64_t)yw * W + xw + c4) = v;
+                if (m < a.Cout && xw + c4 < W) *reinterpret_cast<f32x4*>(Yb + (int64_t)m * HW + (int64_t)yw * W + xw + c4) = v;
             }
         } else if (a.mode == 2) {
             // out[m / 4][2 y + (m % 4) / 2][2 x + m % 2]: lane -> output row (c, i) = lane >> 3, 8 output columns
@@ -282,7 +283,7 @@ conv3x3_f16s_kernel(Conv3F a) {
             const int mrow = 4 * (orow >> 1) + 2 * (orow & 1);
             const f32x4 e = *reinterpret_cast<const f32x4*>(&sl[mrow * C3_SCR_LD + 4 * seg]);
             const f32x4 o = *reinterpret_cast<const f32x4*>(&sl[(mrow + 1) * C3_SCR_LD + 4 * seg]);
-            if (mbase + mrow < a.Cout) {
+            if (mbase + mrow < a.Cout && xw + 4 * seg < W) {
                 float* dst = Yb + (int64_t)((mbase + mrow) / 4) * 4 * HW + (int64_t)(2 * yw + (orow & 1)) * 2 * W + 2 * xw + 8 * seg;
                 *reinterpret_cast<f32x4*>(dst) = f32x4{e.x, o.x, e.y, o.y};
                 *reinterpret_cast<f32x4*>(dst + 4) = f32x4{e.z, o.z, e.w, o.w};
@@ -292,7 +293,7 @@ conv3x3_f16s_kernel(Conv3F a) {
             const int row = lane >> 2, part = lane & 3, m = mbase + row;
             const f32x4 p0 = *reinterpret_cast<const f32x4*>(&sl[row * C3_SCR_LD + 8 * part]);
             const f32x4 p1 = *reinterpret_cast<const f32x4*>(&sl[row * C3_SCR_LD + 8 * part + 4]);
-            if (m < a.Cout) {
+            if (m < a.Cout && xw + 8 * part < W) {
                 float* dst = Yb + (int64_t)(4 * m + 2 * (yw & 1)) * (HW / 4) + (int64_t)(yw >> 1) * (W / 2) + ((xw + 8 * part) >> 1);
                 *reinterpret_cast<f32x4*>(dst) = f32x4{p0.x, p0.z, p1.x, p1.z};
                 *reinterpret_cast<f32x4*>(dst + HW / 4) = f32x4{p0.y, p0.w, p1.y, p1.w};
@@ -379,11 +380,16 @@ int c3_pick_rt(int M) {
 
 }  // namespace
 
+// tile: 128 pixels = TH rows x TW columns.  Images 32 or 64 pixels wide (with a height in whole tiles) get 4 or 2 rows per
+// tile; every other width a multiple of 8 gets tiles of one row x 128 columns, the last tile of a row partly outside
+// the image (its pixels converted to zeros, its stores masked): 40 ... 960-pixel levels of tiled windows and frames.
+static int c3_tile_width(int H, int W) {
+    if ((W == 32 && H % 4 == 0) || (W == 64 && H % 2 == 0)) return W;
+    return 128;
+}
 bool conv3x3_f16s_supported(int Cin, int Cout, int H, int W, int mode) {
     if (Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return false;
-    if (W % 32 != 0 || (W > 128 && W % 128 != 0) || (W < 128 && 128 % W != 0)) return false;
-    const int TW = W < 128 ? W : 128, TH = 128 / TW;
-    if (H % TH != 0) return false;
+    if (W % 8 != 0) return false;
     if (mode == 1 && (H % 2 != 0)) return false;
     if (mode == 2 && Cout % 4 != 0) return false;
     return mode >= 0 && mode <= 2;
@@ -397,7 +403,7 @@ int conv3x3_f16s_launch(const float* x, const float* w, const float* bias, float
                         int mode, void* ws, size_t ws_bytes, hipStream_t stream) {
     RST_REQUIRE(x && w && y && B > 0 && B <= 65535, "conv3x3: bad operand");
     RST_REQUIRE(conv3x3_f16s_supported(Cin, Cout, H, W, mode),
-                "conv3x3: unsupported shape Cin=%d Cout=%d H=%d W=%d mode=%d (W a multiple of 128, or 32 / 64 with H a multiple of 4 / 2)", Cin, Cout, H, W, mode);
+                "conv3x3: unsupported shape Cin=%d Cout=%d H=%d W=%d mode=%d (W a multiple of 8; unshuffle: even H; shuffle: Cout %% 4 == 0)", Cin, Cout, H, W, mode);
     RST_REQUIRE(aligned16(x) && aligned16(y), "conv3x3: tensors must be 16-byte aligned");
     if (ws == nullptr || ws_bytes < conv3x3_f16s_ws_bytes(Cin, Cout) || !aligned16(ws))
         return fail(RST_ERR_WORKSPACE, "conv3x3: workspace %zu < %zu bytes", ws_bytes, conv3x3_f16s_ws_bytes(Cin, Cout));
@@ -421,12 +427,12 @@ int conv3x3_f16s_launch(const float* x, const float* w, const float* bias, float
     Conv3F a{};
     a.x = x; a.afrag = ws; a.bias = bias; a.y = y;
     a.Cin = Cin; a.Cout = Cout; a.H = H; a.W = W; a.mode = mode;
-    a.TW = W < 128 ? W : 128; a.TH = 128 / a.TW;
+    a.TW = c3_tile_width(H, W); a.TH = 128 / a.TW;
     a.kch = (int)cdiv(Cin, 32);
     a.mtiles = (int)cdiv(Cout, 16);
     const int rt = c3_pick_rt(Cout);
     a.mblocks = (int)cdiv(Cout, 32 * rt);
-    a.tiles_x = W / a.TW; a.tiles_y = H / a.TH;
+    a.tiles_x = (int)cdiv(W, a.TW); a.tiles_y = H / a.TH;
     hipLaunchKernelGGL(conv3x3_f16s_prep_kernel, dim3((unsigned)a.mtiles, (unsigned)(9 * a.kch)), dim3(64), 0, stream, w, Cout, Cin,
                        a.kch, static_cast<c3_h8*>(ws));
     RST_LAUNCH_CHECK();

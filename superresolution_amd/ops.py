@@ -290,10 +290,35 @@ def pixel_shuffle2(x):
 # ----------------------------------------------------------------------------
 # dense 3x3 convolution with few output channels (+ residual): the last layer
 # ----------------------------------------------------------------------------
+def conv3x3_backward(x, dy, weight, mode: int, want_dx: bool, want_bias: bool):
+    """Gradients of conv2d(x, weight, bias, padding=1) (+ PixelUnshuffle(2) / PixelShuffle(2) for mode 1 / 2) from the
+    gradient of its output: (dx or None, dweight, dbias or None) through rst_conv3x3_bwd (exact-fp32 products); shapes it
+    does not take (W not a multiple of 4) go through torch's convolution gradients."""
+    lib = _lib.load()
+    x, dy, w = _require(x, "conv3x3 x"), _require(dy, "conv3x3 dy"), _require(weight, "conv3x3 weight")
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    nb = lib.rst_conv3x3_bwd_workspace_bytes(B, Cin, Cout, H, W, int(mode), int(want_dx), int(want_bias))
+    if nb == 0:
+        if mode == 1:
+            dy = _shuffle_raw(dy)           # gradient of PixelUnshuffle is PixelShuffle
+        elif mode == 2:
+            dy = _unshuffle_raw(dy)
+        dx = torch.nn.grad.conv2d_input(x.shape, w, dy, padding=1) if want_dx else None
+        return dx, torch.nn.grad.conv2d_weight(x, w.shape, dy, padding=1), (dy.sum(dim=(0, 2, 3)) if want_bias else None)
+    ws = workspace(nb, x.device)
+    dx = torch.empty_like(x) if want_dx else None
+    dw = torch.empty_like(w)
+    db = torch.empty(Cout, dtype=x.dtype, device=x.device) if want_bias else None
+    check(lib.rst_conv3x3_bwd(_ptr(x), _ptr(dy), _ptr(w), _ptr(dx), _ptr(dw), _ptr(db), B, Cin, Cout, H, W, int(mode), _ptr(ws),
+                              ws.numel(), _stream()), "rst_conv3x3_bwd")
+    return dx, dw, db
+
+
 class _Conv3x3FewOutFn(torch.autograd.Function):
     """y = conv2d(x, weight, bias, padding=1) (+ residual) for 1..4 output channels
     (reference: `self.output` and the `+ base` after it, model/Restromer.py:381-383,431).
-    Forward is the HIP kernel; the gradients are torch's convolution gradients."""
+    Forward and backward (rst_conv3x3_bwd) are HIP kernels."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, residual):
@@ -322,9 +347,7 @@ class _Conv3x3FewOutFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
-        dx = torch.nn.grad.conv2d_input(x.shape, w, dy, padding=1) if ctx.needs_input_grad[0] else None
-        dw = torch.nn.grad.conv2d_weight(x, w.shape, dy, padding=1) if ctx.needs_input_grad[1] else None
-        db = dy.sum(dim=(0, 2, 3)) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        dx, dw, db = conv3x3_backward(x, dy, w, 0, ctx.needs_input_grad[0], ctx.has_bias and ctx.needs_input_grad[2])
         dr = dy if ctx.has_res and ctx.needs_input_grad[3] else None
         return dx, dw, db, dr
 
@@ -361,10 +384,7 @@ class _Conv3x3FewOutUpFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        dy = dy.contiguous()
-        dx = torch.nn.grad.conv2d_input(x.shape, w, dy, padding=1) if ctx.needs_input_grad[0] else None
-        dw = torch.nn.grad.conv2d_weight(x, w.shape, dy, padding=1) if ctx.needs_input_grad[1] else None
-        db = dy.sum(dim=(0, 2, 3)) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        dx, dw, db = conv3x3_backward(x, dy.contiguous(), w, 0, ctx.needs_input_grad[0], ctx.has_bias and ctx.needs_input_grad[2])
         return dx, dw, db, None
 
 
@@ -385,8 +405,8 @@ def conv3x3_supported(x, weight, mode: int) -> bool:
 
 class _Conv3x3Fn(torch.autograd.Function):
     """conv2d(x, weight, bias, padding=1) followed by nothing (mode 0), nn.PixelUnshuffle(2) (mode 1) or
-    nn.PixelShuffle(2) (mode 2): reference model/Restromer.py:181-183, 188-200, 203-215.  Forward is one HIP kernel;
-    the gradients are torch's convolution gradients of the un-shuffled output gradient."""
+    nn.PixelShuffle(2) (mode 2): reference model/Restromer.py:181-183, 188-200, 203-215.  Forward is one HIP kernel,
+    the backward rst_conv3x3_bwd."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, mode):
@@ -410,14 +430,7 @@ class _Conv3x3Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        dy = _require(dy, "conv3x3 dy")
-        if ctx.mode == 1:
-            dy = _shuffle_raw(dy)           # gradient of PixelUnshuffle is PixelShuffle
-        elif ctx.mode == 2:
-            dy = _unshuffle_raw(dy)
-        dx = torch.nn.grad.conv2d_input(x.shape, w, dy, padding=1) if ctx.needs_input_grad[0] else None
-        dw = torch.nn.grad.conv2d_weight(x, w.shape, dy, padding=1) if ctx.needs_input_grad[1] else None
-        db = dy.sum(dim=(0, 2, 3)) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        dx, dw, db = conv3x3_backward(x, dy.contiguous(), w, ctx.mode, ctx.needs_input_grad[0], ctx.has_bias and ctx.needs_input_grad[2])
         return dx, dw, db, None
 
 

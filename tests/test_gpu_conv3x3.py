@@ -1,6 +1,7 @@
 """Dense 3x3 convolution with the pixel (un)shuffle epilogue (rst_conv3x3_fwd) against the oracle's conv3x3 +
-pixel_unshuffle2 / pixel_shuffle2 in fp64, at every tile geometry the kernel has (W = 32, 64, 128, 256), channel
-counts that pad (3, 24, 48), the network's own shapes, and gradients through the Python mirror."""
+pixel_unshuffle2 / pixel_shuffle2 in fp64, at every tile geometry the kernel has (W = 32, 64, 128, 256 and widths
+whose last tile is partial: 40 ... 960), channel counts that pad (3, 24, 48), the network's own shapes; and its
+backward (rst_conv3x3_bwd: dx, dW, db) against the fp64 oracle's autograd at the same shapes."""
 import pytest
 import torch
 
@@ -21,6 +22,12 @@ CASES = [  # B, Cin, Cout, H, W, mode, bias
     # few input channels: the direct fp32 kernel (one row, narrow rows, 1 / 2 / 4 channels, an output count of 4 k)
     (2, 3, 48, 1, 128, 0, True), (1, 3, 48, 8, 32, 0, False), (1, 1, 8, 4, 64, 0, True), (2, 2, 12, 4, 128, 0, False),
     (1, 4, 20, 2, 256, 0, True), (1, 3, 6, 4, 64, 0, True),   # 6 outputs: not a multiple of 4, stays on the matrix kernel
+    # widths that are not whole tiles (the last 128-pixel tile of a row partly outside the image): the levels of a
+    # 320-pixel tiled window (320 / 160 / 80 / 40) and of a 3840-pixel frame (960 / 480)
+    (1, 384, 768, 5, 40, 2, False), (1, 192, 96, 6, 80, 1, False), (1, 96, 48, 4, 160, 1, True), (1, 48, 24, 6, 320, 1, False),
+    (1, 96, 192, 3, 480, 2, False), (1, 48, 40, 3, 960, 0, True), (2, 96, 192, 7, 320, 2, False), (2, 3, 48, 5, 40, 0, True),
+    (1, 48, 24, 30, 32, 1, False),          # 32 wide, height not in whole 4-row tiles: rows of one 128-pixel tile
+    (1, 33, 20, 3, 72, 2, True), (1, 24, 48, 9, 136, 0, False),
 ]
 
 
@@ -65,9 +72,11 @@ def test_conv3x3_gradients_match_torch():
 
 def test_unsupported_width_is_reported():
     from superresolution_amd import ops
-    assert not ops.conv3x3_supported(torch.zeros(1, 8, 8, 40, device="cuda"), torch.zeros(8, 8, 3, 3, device="cuda"), 0)
+    for W in (40, 80, 160, 320, 480, 960):        # the levels of 320-pixel tiled windows and of a 3840-pixel frame
+        assert ops.conv3x3_supported(torch.zeros(1, 8, 8, W, device="cuda"), torch.zeros(8, 8, 3, 3, device="cuda"), 0)
+    assert not ops.conv3x3_supported(torch.zeros(1, 8, 8, 36, device="cuda"), torch.zeros(8, 8, 3, 3, device="cuda"), 0)
     with pytest.raises(RuntimeError):
-        ops.conv3x3(torch.zeros(1, 8, 8, 40, device="cuda"), torch.zeros(8, 8, 3, 3, device="cuda"), None, 0)
+        ops.conv3x3(torch.zeros(1, 8, 8, 36, device="cuda"), torch.zeros(8, 8, 3, 3, device="cuda"), None, 0)
 
 
 @pytest.mark.parametrize("shape", [(2, 48, 3, 16, 24), (1, 12, 4, 6, 10), (1, 48, 3, 8, 128)])
@@ -109,3 +118,29 @@ def test_conv1x1_of_a_concatenation_vs_oracle(Ca, Cb, Cout, N):
     (ops.conv1x1(torch.cat([a2, b2], 1), w2, None) * r).sum().backward()
     assert torch.allclose(ac.grad, a2.grad, rtol=1e-4, atol=1e-5) and torch.allclose(bc.grad, b2.grad, rtol=1e-4, atol=1e-5)
     assert torch.allclose(wc.grad, w2.grad, rtol=1e-4, atol=1e-4)
+
+
+BWD_CASES = [c for c in CASES if c[4] % 4 == 0] + [(8, 96, 192, 16, 16, 2, False), (2, 48, 3, 12, 40, 0, True), (1, 48, 3, 6, 128, 0, False)]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,mode,bias", BWD_CASES)
+def test_conv3x3_backward_vs_oracle(B, Cin, Cout, H, W, mode, bias):
+    """dx, dW, db of conv3x3 (+ shuffle) through rst_conv3x3_bwd against fp64 autograd of the oracle, with an output
+    gradient of the size a mean loss produces (1e-6: the range where an f16-split product would lose its accuracy)."""
+    from oracle import restormer_oracle as orc
+    from superresolution_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + Cin + Cout + H + W + mode + 5)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    b64 = torch.zeros(Cout, dtype=torch.float64, requires_grad=True)
+    y = {0: lambda t: t, 1: orc.pixel_unshuffle2, 2: orc.pixel_shuffle2}[mode](orc.conv3x3(x64, w64, b64))
+    dy = torch.randn(y.shape, generator=g) * 1e-6
+    dx_ref, dw_ref, db_ref = torch.autograd.grad(y, (x64, w64, b64), dy.double())
+    dx, dw, db = ops.conv3x3_backward(x.cuda(), dy.cuda(), w.cuda(), mode, True, bias)
+    assert float((dx.double().cpu() - dx_ref).abs().max() / dx_ref.abs().max()) < TOL
+    assert float((dw.double().cpu() - dw_ref).abs().max() / dw_ref.abs().max()) < TOL
+    if bias:
+        assert float((db.double().cpu() - db_ref).abs().max() / db_ref.abs().max()) < TOL
+    else:
+        assert db is None
