@@ -62,6 +62,16 @@ const char* rst_last_error(void);
 /* library first looked), 0 (the default) if every call keeps to its `stream`.  */
 /* No counterpart in the reference, which never names a stream.                  */
 int rst_bwd_side_stream_enabled(void);
+/* The fp32 entry points run their large products on the f16 matrix instructions  */
+/* with both operands split in two (22 significant bits; see gemm_f16s.hip), which */
+/* needs |activation| < 65504: beyond it the results are inf / NaN.                */
+/* rst_set_exact_fp32(1) keeps every product of this process on the exact-fp32     */
+/* instruction from the next call on (slower; no range limit; weights prepared by   */
+/* rst_block_prepare under the other setting must be prepared again), 0 switches    */
+/* back; unset, RST_F32_MFMA=1 in the environment has the same effect.  No           */
+/* counterpart in the reference, whose fp32 has no such limit.                      */
+void rst_set_exact_fp32(int32_t on);
+int32_t rst_get_exact_fp32(void);
 
 /* ------------------------------------------------------------------------- */
 /* Shapes and parameters of one TransformerBlock                              */

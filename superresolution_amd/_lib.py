@@ -46,6 +46,8 @@ _GR = POINTER(BlockGrads)
 SIGNATURES = {
     "rst_version": (c_int32, []),
     "rst_bwd_side_stream_enabled": (c_int32, []),
+    "rst_set_exact_fp32": (None, [c_int32]),
+    "rst_get_exact_fp32": (c_int32, []),
     "rst_last_error": (c_char_p, []),
     "rst_layernorm_fwd": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int64, _P]),
     "rst_layernorm_bwd_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int64]),

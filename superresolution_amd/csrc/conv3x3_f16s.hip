@@ -460,7 +460,8 @@ size_t rst_conv3x3_workspace_bytes(int32_t Cin, int32_t Cout) {
     return (Cin > 0 && Cout > 0) ? rst::conv3x3_f16s_ws_bytes(Cin, Cout) : 0;
 }
 int32_t rst_conv3x3_supported(int32_t Cin, int32_t Cout, int32_t H, int32_t W, int32_t shuffle_mode) {
-    return rst::conv3x3_f16s_supported(Cin, Cout, H, W, shuffle_mode) ? 1 : 0;
+    // (with the exact-fp32 switch on there is no kernel for it here: callers fall back to their own convolution)
+    return rst::gemm_f16s_enabled() && rst::conv3x3_f16s_supported(Cin, Cout, H, W, shuffle_mode) ? 1 : 0;
 }
 int rst_conv3x3_fwd(const float* x, const float* weight, const float* bias, float* y, int32_t B, int32_t Cin, int32_t Cout,
                     int32_t H, int32_t W, int32_t shuffle_mode, void* workspace, size_t workspace_bytes, void* stream) {

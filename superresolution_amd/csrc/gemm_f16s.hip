@@ -14,6 +14,7 @@
 // 8 waves = 2 row halves x 4 pixel quarters, block tile (32 RT rows) x 128 pixels, 3-deep ring, one barrier per chunk.
 // |x| must stay below 65504 (f16 range); RST_F32_MFMA=1 keeps every product on the exact-fp32 kernels.
 #include "kernels.hpp"
+#include <atomic>
 
 namespace rst {
 
@@ -301,10 +302,15 @@ int gf_pick_rt(int M) {
 
 size_t gemm_f16s_frag_bytes(int M, int K) { return (size_t)round_up(M, 16) * (size_t)round_up(K, 32) * 4; }
 
+// -1: not set by the caller, RST_F32_MFMA in the environment decides; 0 / 1: rst_set_exact_fp32
+static std::atomic<int> g_exact_fp32{-1};
 bool gemm_f16s_enabled() {
+    const int e = g_exact_fp32.load(std::memory_order_relaxed);
+    if (e >= 0) return e == 0;
     static const bool off = getenv("RST_F32_MFMA") != nullptr && getenv("RST_F32_MFMA")[0] == '1';
     return !off;
 }
+void set_exact_fp32(int on) { g_exact_fp32.store(on ? 1 : 0, std::memory_order_relaxed); }
 
 bool gemm_f16s_supported(const GemmNN& g) {
     const bool al = aligned16(g.X) && aligned16(g.Y) && (g.R == nullptr || aligned16(g.R));
@@ -366,3 +372,8 @@ int gemm_f16s_launch(const GemmNN& g, hipStream_t stream) {
 }
 
 }  // namespace rst
+
+extern "C" {
+void rst_set_exact_fp32(int32_t on) { rst::set_exact_fp32(on); }
+int32_t rst_get_exact_fp32(void) { return rst::gemm_f16s_enabled() ? 0 : 1; }
+}

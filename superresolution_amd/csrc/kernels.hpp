@@ -45,7 +45,8 @@ struct GemmNN {
 int gemm_nn_launch(const GemmNN& g, hipStream_t stream);
 // gemm_f16s.hip
 size_t gemm_f16s_frag_bytes(int M, int K);
-bool gemm_f16s_enabled();                       // false under RST_F32_MFMA=1
+bool gemm_f16s_enabled();                       // false under RST_F32_MFMA=1 or after rst_set_exact_fp32(1)
+void set_exact_fp32(int on);
 bool gemm_f16s_supported(const GemmNN& g);      // strides / alignment of X, Y, R
 // w: nb matrices [M][K] (row stride lda; transA: stored [K][M]) w_bs elements apart -> fragments frag_bs_bytes apart;
 // gamma (optional) scales column k; with s, c: s[m] = sum_k of the split folded row, c[m] = sum_k w[m][k] beta[k] + bias[m]

@@ -598,7 +598,7 @@ int pwdw_launch(const PwDw& a, hipStream_t stream) {
     // forms of that: wave-specialised (pwdw_ws, 96 input channels: 685 / 503 us plain / gated at 16 x 96 x 256 x 256)
     // and single-role (pwdw_f16: 705 / 537 us there, but ahead at 48 channels).  RST_PWDW_FORM=f / w forces one (tests).
     static const char* form_env = getenv("RST_PWDW_FORM");
-    static const bool f32_mfma = getenv("RST_F32_MFMA") != nullptr && getenv("RST_F32_MFMA")[0] == '1';
+    const bool f32_mfma = !gemm_f16s_enabled();
     const bool single = form_env != nullptr ? form_env[0] == 'f' : a.K == 48;
     if (!f32_mfma && single && pwdw_f16_supported(a)) return pwdw_f16_launch(a, stream);
     if (pwdw_ws_supported(a)) return pwdw_ws_launch(a, stream);

@@ -35,7 +35,7 @@ int pwdw_ws_launch(const PwDw& a, hipStream_t stream) {
     // 96 input channels: the product runs on the f16 matrix instructions with both operands split in two (fp32
     // accuracy, see pwdw_ws_kernel.hpp); RST_F32_MFMA=1 keeps the exact-fp32 instructions (A/B runs, inputs beyond the
     // f16 range)
-    static const bool f32_mfma = getenv("RST_F32_MFMA") != nullptr && getenv("RST_F32_MFMA")[0] == '1';
+    const bool f32_mfma = !gemm_f16s_enabled();
     const bool f16s = KS == 24 && !f32_mfma;
     const void* kern = a.gate ? pwdw_ws_gate_kernel(KS, f16s)
                      : KS == 24 ? (f16s ? reinterpret_cast<const void*>(&pwdw_ws_kernel<24, 6, false, true>)

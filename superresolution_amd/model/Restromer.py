@@ -407,8 +407,47 @@ class Restormer(nn.Module):
             # on an fp32 copy of the input, result in the input's dtype -- the reference module runs under
             # autocast through ordinary torch operators, so such a call must not fail.
             with torch.autocast("cuda", enabled=False):
-                return self._forward_fp32(inp_img.float()).to(inp_img.dtype)
-        return self._forward_fp32(inp_img)
+                return self._forward_fp32_guarded(inp_img.float()).to(inp_img.dtype)
+        return self._forward_fp32_guarded(inp_img)
+
+    # The fp32 kernels multiply on the f16 matrix instructions with both operands split in two (fp32 accuracy), which
+    # needs |activation| < 65504; beyond that a product returns inf / NaN, and non-finite values reach the output.  An
+    # inference call therefore looks at its result once and, if it is not finite although the input was, runs again on
+    # the exact-fp32 instructions (and keeps to them: `model.exact_fp32`).  The look is a device-to-host read of one
+    # flag, i.e. a synchronisation: free when the call keeps the GPU busy longer than the host needs to queue it, not
+    # free for small inputs -- range_check None (default) checks calls of at least 2^19 input pixels, True always,
+    # False never; RST_RANGE_CHECK=0 / 1 in the environment overrides the attribute.
+    range_check = None
+    exact_fp32 = False
+
+    def _range_check_wanted(self, inp_img) -> bool:
+        if torch.is_grad_enabled() or not inp_img.is_cuda or torch.cuda.is_current_stream_capturing():
+            return False
+        env = os.environ.get("RST_RANGE_CHECK")
+        want = self.range_check if env is None else env == "1"
+        if want is None:
+            want = inp_img.shape[0] * inp_img.shape[-2] * inp_img.shape[-1] >= (1 << 19)
+        return bool(want)
+
+    def _forward_fp32_guarded(self, inp_img):
+        from .. import _lib
+        lib = _lib.load() if inp_img.is_cuda else None
+        if lib is None or lib.rst_get_exact_fp32():
+            return self._forward_fp32(inp_img)
+        if self.exact_fp32:
+            lib.rst_set_exact_fp32(1)
+            try:
+                return self._forward_fp32(inp_img)
+            finally:
+                lib.rst_set_exact_fp32(0)
+        out = self._forward_fp32(inp_img)
+        if self._range_check_wanted(inp_img) and not bool(torch.isfinite(out).all()) and bool(torch.isfinite(inp_img).all()):
+            import warnings
+            warnings.warn("Restormer: an activation left the f16 range of the split-f16 products (|x| >= 65504); this model "
+                          "now runs its fp32 products on the exact-fp32 instructions (model.exact_fp32 = True)")
+            self.exact_fp32 = True
+            return self._forward_fp32_guarded(inp_img)
+        return out
 
     def _forward_bf16_train(self, inp_img):
         """Differentiable forward with bf16 activations (BASELINE config 3: bf16 storage, fp32 sums, fp32 master

@@ -554,7 +554,9 @@ class PreparedBlock:
 
     @staticmethod
     def _key(tensors, device):
-        return tuple((n, t.data_ptr(), t._version) for n, t in tensors.items() if t is not None) + (str(device),)
+        # (the prepared form depends on which instructions the products run on: rst_set_exact_fp32)
+        return (tuple((n, t.data_ptr(), t._version) for n, t in tensors.items() if t is not None) +
+                (str(device), int(_lib.load().rst_get_exact_fp32())))
 
     def is_current(self, tensors, device) -> bool:
         """True when the kept buffer was prepared from exactly these parameter tensors (nothing would be launched)."""

@@ -115,3 +115,47 @@ def test_data_parallel_trainer_single_gpu():
     tr = DataParallelTrainer(net, world_size=1)
     losses = [tr.step(x, tgt).item() for _ in range(3)]
     assert np.allclose(losses, g["losses"], rtol=2e-5), (losses, g["losses"])
+
+
+def test_activations_beyond_the_f16_range_never_return_inf():
+    """The fp32 products run on the f16 matrix instructions with split operands: |activation| must stay below 65504.  An
+    image scaled by 1e5 leaves that range in the first block.  With the range check on, the module notices the
+    non-finite result, switches itself to the exact-fp32 instructions and returns what the fp64 oracle computes; the C
+    switch (rst_set_exact_fp32) does the same for direct callers of the block entry points."""
+    import warnings
+    from oracle import recipe
+    from oracle import restormer_oracle as orc
+    from superresolution_amd import _lib
+    from superresolution_amd.model.Restromer import Restormer
+    case = recipe.MODEL_CASES[1]
+    sd, x, _ = recipe.model_case_tensors(case, torch.float32)
+    x = x * 1e5
+    net = Restormer(**case[1]); net.load_state_dict(sd, strict=True); net = net.cuda().eval()
+    with torch.no_grad():
+        ref = orc.restormer_forward(x.double(), {k: v.double() for k, v in sd.items()})
+        net.range_check = False
+        raw = net(x.cuda())
+        assert not bool(torch.isfinite(raw).all())                 # what the guard is for
+        net.range_check = True
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            got = net(x.cuda())
+        assert any("f16 range" in str(m.message) for m in w) and net.exact_fp32
+        assert bool(torch.isfinite(got).all())
+        assert float((got.double().cpu() - ref).abs().max() / ref.abs().max()) < 1e-4
+        assert _lib.load().rst_get_exact_fp32() == 0               # the switch is back for everyone else
+        again = net(x.cuda())                                      # stays on the exact instructions, silently
+        # (not bit for bit: in this mode the dense 3x3 convolutions are torch's, whose algorithm choice may differ per call)
+        assert float((again - got).abs().max() / got.abs().max()) < 1e-5
+        # the C switch for callers of the block entry points
+        blk = net.encoder_level1[0]
+        h = net.patch_embed(x.cuda())
+        assert float(h.abs().max()) > 65504
+        lib = _lib.load()
+        lib.rst_set_exact_fp32(1)
+        try:
+            assert lib.rst_get_exact_fp32() == 1
+            y = blk(h)
+        finally:
+            lib.rst_set_exact_fp32(0)
+        assert bool(torch.isfinite(y).all())
