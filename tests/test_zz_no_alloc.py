@@ -21,11 +21,17 @@ def _both(lib, B, C, H, W, with_bias, seed):
         db = torch.full((C,), float("nan"), device="cuda")
         st = torch.cuda.current_stream().cuda_stream
         if noalloc:
-            before = torch.cuda.memory_allocated()
-            check(lib.rst_layernorm_bwd_noalloc(x.data_ptr(), w.data_ptr(), int(with_bias), dy.data_ptr(), dx.data_ptr(), 0,
-                                                dw.data_ptr(), db.data_ptr() if with_bias else None, B, C, N, st),
-                  "rst_layernorm_bwd_noalloc")
-            assert torch.cuda.memory_allocated() == before
+            def call():
+                check(lib.rst_layernorm_bwd_noalloc(x.data_ptr(), w.data_ptr(), int(with_bias), dy.data_ptr(), dx.data_ptr(), 0,
+                                                    dw.data_ptr(), db.data_ptr() if with_bias else None, B, C, N, st),
+                      "rst_layernorm_bwd_noalloc")
+            call()                                    # (the first call on a device looks the array's address up)
+            torch.cuda.synchronize()
+            # free device memory as the driver sees it: torch's own counter would not notice a hipMalloc of the library's
+            free_before, reserved_before = torch.cuda.mem_get_info()[0], torch.cuda.memory_reserved()
+            call()
+            torch.cuda.synchronize()
+            assert torch.cuda.memory_reserved() == reserved_before and torch.cuda.mem_get_info()[0] == free_before
         else:
             nb = lib.rst_layernorm_bwd_workspace_bytes(B, C, N)
             ws = torch.empty(nb, dtype=torch.uint8, device="cuda")
