@@ -274,11 +274,14 @@ def side_train_bf16(dev, rank, world, steps=8, warmup=3, B=8, S=128):
     over RCCL, division by the world size, clip, Adam) on 8 x 3 x 128 x 128 per GPU, and the same step with the
     collectives replaced by no-ops -- the difference is what the exchange costs a step."""
     from superresolution_amd.parallel import Collectives, DataParallelTrainer, NullCollectives
+    import torch.distributed as dist
     gen = torch.Generator(device=dev).manual_seed(200 + rank)
     x = torch.rand(B, 3, S, S, device=dev, generator=gen)
     tgt = torch.rand(B, 3, 2 * S, 2 * S, device=dev, generator=gen)
     res = {}
-    for name, comm in (("rccl", Collectives(eager=True)), ("no_exchange", NullCollectives(max(world, 2)))):
+    runs = (("rccl", Collectives(eager=True)), ("no_exchange", NullCollectives(max(world, 2)))) if dist.is_initialized() \
+        else (("plain", None),)          # one process without torch.distributed: no buckets, no exchange
+    for name, comm in runs:
         net = build_model(0).to(dev)
         trainer = DataParallelTrainer(net, world_size=world, comm=comm)
 
@@ -287,6 +290,11 @@ def side_train_bf16(dev, rank, world, steps=8, warmup=3, B=8, S=128):
                 return trainer.step(x, tgt)
         res[name] = _timed(step, steps, warmup, world)
         del trainer, net
+    if "plain" in res:
+        return {"value": round(B * S * S / res["plain"] / 1e6, 3), "unit": "MP/s", "ms_per_step": round(res["plain"] * 1e3, 3),
+                "scaling": "weak", "dtype": "bf16", "steps": steps, "warmup": warmup,
+                "workload": f"bf16 training step (fwd + L1 + bwd + clip + Adam), {B}x3x{S}x{S}, one process without "
+                            f"torch.distributed (under torch.distributed.run this object also times the RCCL all-reduce)"}
     return {"value": round(world * B * S * S / res["rccl"] / 1e6, 3), "unit": "MP/s", "ms_per_step": round(res["rccl"] * 1e3, 3),
             "ms_per_step_without_exchange": round(res["no_exchange"] * 1e3, 3),
             "exposed_allreduce_ms": round((res["rccl"] - res["no_exchange"]) * 1e3, 3), "scaling": "weak", "dtype": "bf16",
@@ -299,7 +307,8 @@ def side_tiled_2048(net, dev, rank, world, steps=3, warmup=1):
     tile t on rank t mod world, the cores gathered on rank 0 (bf16 storage path)."""
     from superresolution_amd.parallel import Collectives, tiled_inference
     img = torch.rand(1, 3, 2048, 2048, device=dev, generator=torch.Generator(device=dev).manual_seed(300)).bfloat16()
-    comm = Collectives(eager=True)
+    import torch.distributed as dist
+    comm = Collectives(eager=dist.is_initialized())
     net.eval()
 
     def step():
@@ -451,14 +460,12 @@ def main():
         out["bf16_storage"]["two_streams"] = {"value": round(world * B * S * S * args.steps / 1e6 / el2, 3), "unit": "MP/s",
                                               "ms_per_step": round(el2 / args.steps * 1e3, 3),
                                               "note": "opt-in (model.two_streams = True): the batch as two half-batches on two HIP streams"}
-        import torch.distributed as dist
-        if dist.is_initialized():
-            # Launched under torch.distributed.run: the default line also carries the two workloads whose data path has
-            # an exchange, run through RCCL as they are (also with one rank), so that a 1/2/4/8-GPU sweep of the default
-            # command records them: BASELINE config 3 (bf16 training step, gradient all-reduce) and config 4 (one
-            # 2048 x 2048 image in tiles dealt to the ranks, cores gathered on rank 0).  Never `value`.
-            out["train_bf16"] = side_train_bf16(dev, rank, world)
-            out["tiled_2048"] = side_tiled_2048(net, dev, rank, world)
+        # The default line also carries the two workloads whose data path has an exchange: BASELINE config 3 (bf16
+        # training step, gradient all-reduce) and config 4 (one 2048 x 2048 image in tiles dealt to the ranks, cores
+        # gathered on rank 0).  Under torch.distributed.run they go through RCCL as they are (also with one rank), so a
+        # 1/2/4/8-GPU sweep of the default command records them; in a plain one-process run they run without.  Never `value`.
+        out["train_bf16"] = side_train_bf16(dev, rank, world)
+        out["tiled_2048"] = side_tiled_2048(net, dev, rank, world)
         if rank == 0:
             # kernels of the training path that the inference workload does not launch, at a headline shape:
             # channel LayerNorm forward and backward (model/Restromer.py:26-52) at 16 x 96 x 256 x 256
