@@ -475,6 +475,26 @@ int rst_bf16_block_bwd_kept(const rst_block_desc* desc, const rst_block_params* 
                             rst_block_grads* grads, const void* kept, void* workspace, size_t workspace_bytes,
                             void* stream);
 
+/* The same pair for a training step that has memory to spend (what autograd keeps   */
+/* of model/Restromer.py:99-104,128-150,163-167: every intermediate of the block):   */
+/* rst_bf16_block_fwd_save evaluates the block with the unfused kernels and leaves,  */
+/* besides the kept attention above, the two 1x1 outputs, their depthwise results,   */
+/* x + attn(...) and the gated product in `saved` -- a caller-owned device buffer of */
+/* rst_bf16_block_saved_bytes (16-byte aligned; the kept attention plus              */
+/* 2*(7*C + 5*pad8(hidden)) bytes per pixel).  y_packed must not alias x_packed.     */
+/* rst_bf16_block_bwd_saved reads them and evaluates nothing again; its workspace    */
+/* (rst_bf16_block_bwd_saved_workspace_bytes) is smaller by those tensors.           */
+/* Gradients as for rst_bf16_block_bwd, of the forward pass that was applied.        */
+size_t rst_bf16_block_saved_bytes(const rst_block_desc* desc);
+size_t rst_bf16_block_bwd_saved_workspace_bytes(const rst_block_desc* desc);
+int rst_bf16_block_fwd_save(const rst_block_desc* desc, const rst_block_params* params,
+                            const void* prepared, const void* x_packed, void* y_packed, void* saved,
+                            void* workspace, size_t workspace_bytes, void* stream);
+int rst_bf16_block_bwd_saved(const rst_block_desc* desc, const rst_block_params* params, const void* prepared,
+                             const void* x_packed, const void* dy_packed, void* dx_packed,
+                             rst_block_grads* grads, const void* saved, void* workspace, size_t workspace_bytes,
+                             void* stream);
+
 /* ------------------------------------------------------------------------- */
 /* Dataset item on the GPU -- replaces LazyRAWDataset.__getitem__,             */
 /* data/loader.py:33-52 (raw / max_val, odd trailing row / column dropped) and  */

@@ -109,6 +109,10 @@ SIGNATURES = {
     "rst_bf16_block_kept_bytes": (c_size_t, [_DESC]),
     "rst_bf16_block_fwd_keep": (c_int32, [_DESC, _PAR, _P, _P, _P, _P, _P, c_size_t, _P]),
     "rst_bf16_block_bwd_kept": (c_int32, [_DESC, _PAR, _P, _P, _P, _P, _GR, _P, _P, c_size_t, _P]),
+    "rst_bf16_block_saved_bytes": (c_size_t, [_DESC]),
+    "rst_bf16_block_bwd_saved_workspace_bytes": (c_size_t, [_DESC]),
+    "rst_bf16_block_fwd_save": (c_int32, [_DESC, _PAR, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "rst_bf16_block_bwd_saved": (c_int32, [_DESC, _PAR, _P, _P, _P, _P, _GR, _P, _P, c_size_t, _P]),
     "rst_bf16_conv3x3_bwd_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
     "rst_bf16_conv3x3_bwd": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, c_size_t, _P]),
     "rst_bf16_conv1x1_bwd_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int64]),

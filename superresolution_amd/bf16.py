@@ -235,15 +235,18 @@ def cat(a: Packed, b: Packed) -> Packed:
 class _StageFn(torch.autograd.Function):
     """A run of TransformerBlocks (one `nn.Sequential` of the network) on bf16 activations, differentiable.
 
-    Forward: the packed bf16 inference kernels (`rst_bf16_block_fwd_keep`, fused); what is kept is each block's INPUT
-    in packed bf16 -- 2 bytes per element and block instead of the ~26 fp32 values per element that the fp32
-    training forward keeps -- and its attention's small matrices (softmax, normalised Gram matrix, norms, the product
-    with project_out: B*C*(C + 2c + 2) floats, nothing that grows with the image; ``RST_BF16_KEEP_ATTN=0``: not even
-    those).  Backward, block by block in reverse: `rst_bf16_block_bwd_kept` evaluates the block again on
-    the kept input (activation recomputation, bf16 storage) and returns the packed bf16 gradient of the input and
-    the fp32 gradients of the parameters.  So: bf16 activations and activation gradients, fp32 sums, fp32 parameters
-    and parameter gradients.  ``RST_BF16_BWD=fp32`` switches the backward to the fp32 kernels on the unpacked input
-    (`ops.block_recompute_backward`: the gradient of the fp32 block at the bf16-rounded activations).
+    Forward, two ways per block.  Saving (`rst_bf16_block_fwd_save`, the default while it fits): the block's input and
+    every intermediate its backward pass reads stay in packed bf16 -- 2 (8 C + 5 hidden) bytes per pixel and block; a
+    288 GB device holds that for every block of the network at training crop sizes many times over -- and the backward
+    pass (`rst_bf16_block_bwd_saved`) evaluates nothing again.  Recomputing (`rst_bf16_block_fwd_keep`, the fused
+    inference kernels): what is kept is the block's INPUT only -- 2 bytes per element and block -- and its
+    attention's small matrices (softmax, normalised Gram matrix, norms, the product with project_out:
+    B*C*(C + 2c + 2) floats, nothing that grows with the image; ``RST_BF16_KEEP_ATTN=0``: not even those);
+    `rst_bf16_block_bwd_kept` evaluates the block again on the kept input.  ``RST_BF16_SAVE=1`` / ``0`` forces one or
+    the other; by default a stage saves as long as its blocks' buffers stay within a quarter of the device memory
+    that is free when the stage starts.  Either way: bf16 activations and activation gradients, fp32 sums, fp32
+    parameters and parameter gradients.  ``RST_BF16_BWD=fp32`` switches the backward to the fp32 kernels on the
+    unpacked input (`ops.block_recompute_backward`: the gradient of the fp32 block at the bf16-rounded activations).
     x: (B, C, H, W) bf16."""
 
     @staticmethod
@@ -256,21 +259,41 @@ class _StageFn(torch.autograd.Function):
         # tensors and gets packed tensors back, gradients included
         ctx.packed_io = x.dim() == 5
         p = Packed(x.contiguous(), x.shape[1] * 8) if ctx.packed_io else pack(x)
-        kept, attn = [], []
+        kept, attn, modes = [], [], []
         keep_attn = os.environ.get("RST_BF16_KEEP_ATTN", "1") != "0"
+        fp32_bwd = os.environ.get("RST_BF16_BWD", "bf16") == "fp32"
+        save = os.environ.get("RST_BF16_SAVE", "auto")
+        budget = 0
+        if fp32_bwd or save == "0":
+            budget = 0
+        elif save == "1":
+            budget = 1 << 62
+        else:
+            free, _ = torch.cuda.mem_get_info(p.data.device)
+            free += torch.cuda.memory_reserved(p.data.device) - torch.cuda.memory_allocated(p.data.device)
+            budget = free // 4
         n = len(PARAM_FIELDS)
         for i, (heads, hidden) in enumerate(metas):
             params = dict(zip(PARAM_FIELDS, flat[i * n:(i + 1) * n]))
             kept.append(p.data)
             out = Packed(torch.empty_like(p.data), p.C)
-            a = _block_into(lib, p, out, heads, hidden, params, caches[i], keep_attn)
-            if keep_attn:
-                attn.append(a)
+            need = _saved_bytes(lib, p, heads, hidden, params) if budget > 0 else 0
+            if 0 < need <= budget:
+                budget -= need
+                attn.append(_block_into(lib, p, out, heads, hidden, params, caches[i], save=True))
+                modes.append("saved")
+            elif keep_attn and not fp32_bwd:
+                attn.append(_block_into(lib, p, out, heads, hidden, params, caches[i], keep_attn=True))
+                modes.append("kept")
+            else:
+                _block_into(lib, p, out, heads, hidden, params, caches[i])
+                attn.append(None)
+                modes.append("input")
             p = out
         ctx.metas, ctx.shape, ctx.caches = metas, tuple(p.shape), caches
         ctx.present = [t is not None for t in flat]
-        ctx.keep_attn = keep_attn
-        ctx.save_for_backward(*kept, *attn, *[t for t in flat if t is not None])
+        ctx.modes = modes
+        ctx.save_for_backward(*kept, *[a for a in attn if a is not None], *[t for t in flat if t is not None])
         return p.data if ctx.packed_io else unpack(p, torch.bfloat16)
 
     @staticmethod
@@ -278,8 +301,9 @@ class _StageFn(torch.autograd.Function):
         import os
         lib = _lib.load()
         nb = len(ctx.metas)
-        na = nb if ctx.keep_attn else 0
-        kept, attn, rest = ctx.saved_tensors[:nb], ctx.saved_tensors[nb:nb + na], iter(ctx.saved_tensors[nb + na:])
+        na = sum(m != "input" for m in ctx.modes)
+        kept, bufs, rest = ctx.saved_tensors[:nb], iter(ctx.saved_tensors[nb:nb + na]), iter(ctx.saved_tensors[nb + na:])
+        attn = [None if m == "input" else next(bufs) for m in ctx.modes]
         flat = [next(rest) if pr else None for pr in ctx.present]
         B, C, H, W = ctx.shape
         n = len(PARAM_FIELDS)
@@ -299,24 +323,30 @@ class _StageFn(torch.autograd.Function):
         for i in reversed(range(nb)):
             heads, hidden = ctx.metas[i]
             params = dict(zip(PARAM_FIELDS, flat[i * n:(i + 1) * n]))
-            g, pg = block_backward(Packed(kept[i], C), g, heads, hidden, params, ctx.caches[i], attn[i] if na else None)
+            g, pg = block_backward(Packed(kept[i], C), g, heads, hidden, params, ctx.caches[i],
+                                   kept_attn=attn[i] if ctx.modes[i] == "kept" else None,
+                                   saved=attn[i] if ctx.modes[i] == "saved" else None)
             for j, name in enumerate(PARAM_FIELDS):
                 grads[i * n + j] = pg[name]
         return ((g.data if ctx.packed_io else unpack(g, torch.bfloat16)), None, None) + tuple(grads)
 
 
 def block_backward(x: Packed, dy: Packed, heads: int, hidden: int, params: Dict[str, Optional[torch.Tensor]],
-                   cache: Optional[PreparedCache] = None, kept_attn: Optional[torch.Tensor] = None):
+                   cache: Optional[PreparedCache] = None, kept_attn: Optional[torch.Tensor] = None,
+                   saved: Optional[torch.Tensor] = None):
     """Gradients of one TransformerBlock from its packed bf16 input and the packed gradient of its output
     (`rst_bf16_block_bwd`).  Returns (dx packed, {parameter name: fp32 gradient or None}).  With the block's `cache`
     the weights prepared for the forward pass are used again (they are rebuilt if a parameter changed since); with
     `kept_attn` (what `block_forward_keep` returned for this input) the attention is not formed again
-    (`rst_bf16_block_bwd_kept`)."""
+    (`rst_bf16_block_bwd_kept`); with `saved` (what `block_forward_save` returned) nothing is
+    (`rst_bf16_block_bwd_saved`)."""
     lib = _lib.load()
     B, C, H, W = x.shape
     tensors = {n: _f32(None if params.get(n) is None else params[n].detach(), n) for n in PARAM_FIELDS}
     desc = make_desc(B, C, H, W, heads, hidden, tensors["norm1_bias"] is not None, tensors["qkv_bias"] is not None)
-    nb = lib.rst_bf16_block_bwd_workspace_bytes(ctypes.byref(desc))
+    if saved is not None and kept_attn is not None:
+        raise RuntimeError("bf16 block backward: either the kept attention or the saved activations")
+    nb = (lib.rst_bf16_block_bwd_saved_workspace_bytes if saved is not None else lib.rst_bf16_block_bwd_workspace_bytes)(ctypes.byref(desc))
     if nb == 0:
         raise RuntimeError("bf16 block backward: " + lib.rst_last_error().decode("utf-8", "replace"))
     par = _fill(BlockParams(), tensors)
@@ -327,7 +357,12 @@ def block_backward(x: Packed, dy: Packed, heads: int, hidden: int, params: Dict[
         prepared = cache.get(lib, desc, par, {n: params.get(n) for n in PARAM_FIELDS}, x.data.device)
     ws = workspace(nb, x.data.device)
     dx = Packed(torch.empty_like(x.data), x.C)
-    if kept_attn is not None:
+    if saved is not None:
+        if saved.dtype != torch.uint8 or saved.numel() < lib.rst_bf16_block_saved_bytes(ctypes.byref(desc)) or not saved.is_cuda:
+            raise RuntimeError("bf16 block backward: saved activations buffer of the wrong size, type or device")
+        check(lib.rst_bf16_block_bwd_saved(ctypes.byref(desc), ctypes.byref(par), _ptr(prepared), _ptr(x.data), _ptr(dy.data), _ptr(dx.data),
+                                           ctypes.byref(gr), _ptr(saved), _ptr(ws), ws.numel(), _stream()), "rst_bf16_block_bwd_saved")
+    elif kept_attn is not None:
         if kept_attn.dtype != torch.uint8 or kept_attn.numel() < lib.rst_bf16_block_kept_bytes(ctypes.byref(desc)) or not kept_attn.is_cuda:
             raise RuntimeError("bf16 block backward: kept attention buffer of the wrong size, type or device")
         check(lib.rst_bf16_block_bwd_kept(ctypes.byref(desc), ctypes.byref(par), _ptr(prepared), _ptr(x.data), _ptr(dy.data), _ptr(dx.data),
@@ -347,7 +382,22 @@ def block_forward_keep(x: Packed, heads: int, hidden: int, params: Dict[str, Opt
     return out, kept
 
 
-def _block_into(lib, src: Packed, dst: Packed, heads, hidden, params, cache, keep_attn=False):
+def block_forward_save(x: Packed, heads: int, hidden: int, params: Dict[str, Optional[torch.Tensor]],
+                       cache: Optional[PreparedCache] = None):
+    """TransformerBlock on a packed tensor for a training step that may spend memory: returns (y packed, saved
+    activations) -- the second is what `block_backward(..., saved=)` wants (`rst_bf16_block_fwd_save`)."""
+    out = Packed(torch.empty_like(x.data), x.C)
+    saved = _block_into(_lib.load(), x, out, heads, hidden, params, cache, save=True)
+    return out, saved
+
+
+def _saved_bytes(lib, src: Packed, heads, hidden, params) -> int:
+    B, C, H, W = src.shape
+    desc = make_desc(B, C, H, W, heads, hidden, params.get("norm1_bias") is not None, params.get("qkv_bias") is not None)
+    return int(lib.rst_bf16_block_saved_bytes(ctypes.byref(desc)))
+
+
+def _block_into(lib, src: Packed, dst: Packed, heads, hidden, params, cache, keep_attn=False, save=False):
     B, C, H, W = src.shape
     tensors = {n: _f32(params.get(n), n) for n in PARAM_FIELDS}
     desc = make_desc(B, C, H, W, heads, hidden, tensors["norm1_bias"] is not None, tensors["qkv_bias"] is not None)
@@ -357,6 +407,11 @@ def _block_into(lib, src: Packed, dst: Packed, heads, hidden, params, cache, kee
     par = _fill(BlockParams(), tensors)
     prepared = cache.get(lib, desc, par, {n: params.get(n) for n in PARAM_FIELDS}, src.data.device) if cache is not None else None
     ws = workspace(nb, src.data.device)
+    if save:
+        saved = torch.empty(lib.rst_bf16_block_saved_bytes(ctypes.byref(desc)), dtype=torch.uint8, device=src.data.device)
+        check(lib.rst_bf16_block_fwd_save(ctypes.byref(desc), ctypes.byref(par), _ptr(prepared), _ptr(src.data), _ptr(dst.data), _ptr(saved),
+                                          _ptr(ws), ws.numel(), _stream()), "rst_bf16_block_fwd_save")
+        return saved
     if keep_attn:
         kept = torch.empty(lib.rst_bf16_block_kept_bytes(ctypes.byref(desc)), dtype=torch.uint8, device=src.data.device)
         check(lib.rst_bf16_block_fwd_keep(ctypes.byref(desc), ctypes.byref(par), _ptr(prepared), _ptr(src.data), _ptr(dst.data), _ptr(kept),

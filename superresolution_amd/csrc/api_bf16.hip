@@ -177,9 +177,29 @@ static size_t pk_block_kept_bytes(const rst_block_desc* d) {
     return cv.total();
 }
 
-// x1 = x + attention(LN1(x));  y = x1 + ffn(LN2(x1))   (model/Restromer.py:163-167), y may alias x
+// What a training forward pass may keep INSTEAD, when memory is no concern: the kept attention plus every intermediate
+// the backward pass reads (packed bf16) -- the two 1x1 outputs t and u, their depthwise results qkv and d, x1 and the
+// gated product g: 2 (7 C + 5 Hp) bytes per pixel and block, against evaluating the block again in the backward pass.
+struct SavedActs { KeptAttn k; bf16_t *t, *qkv, *x1, *u, *d, *g; };
+static SavedActs saved_carve(const rst_block_desc* d, Carve& cv) {
+    const size_t bn = (size_t)d->B * d->H * d->W;
+    const int C = d->C, Hp = pad8(d->hidden);
+    SavedActs s{};
+    s.k = kept_carve(d, cv);
+    s.t = cv.halves(bn * 3 * C); s.qkv = cv.halves(bn * 3 * C); s.x1 = cv.halves(bn * C);
+    s.u = cv.halves(bn * 2 * Hp); s.d = cv.halves(bn * 2 * Hp); s.g = cv.halves(bn * Hp);
+    return s;
+}
+static size_t pk_block_saved_bytes(const rst_block_desc* d) {
+    Carve cv(nullptr);
+    saved_carve(d, cv);
+    return cv.total();
+}
+
+// x1 = x + attention(LN1(x));  y = x1 + ffn(LN2(x1))   (model/Restromer.py:163-167), y may alias x.
+// `kept`: the attention's small matrices are also written there; `saved`: those and every intermediate (never both)
 static int pk_block_fwd(const rst_block_desc* d, const rst_block_params* p, const void* prepared, const bf16_t* x, bf16_t* y,
-                        void* kept, void* ws, size_t ws_bytes, hipStream_t stream) {
+                        void* kept, void* saved, void* ws, size_t ws_bytes, hipStream_t stream) {
     RST_REQUIRE(x && y && p, "bf16 block: null operand");
     RST_REQUIRE(p->temperature && p->proj_weight, "bf16 block: null attention parameter");
     RST_REQUIRE(!d->conv_bias || p->proj_bias, "bf16 block: conv_bias set but a bias is null");
@@ -199,20 +219,33 @@ static int pk_block_fwd(const rst_block_desc* d, const rst_block_params* p, cons
     }
     pk_block_carve(d, cv, b);
     KeptAttn keep{};
+    SavedActs sv{};
+    RST_REQUIRE(kept == nullptr || saved == nullptr, "bf16 block: either the kept attention or the saved activations");
     if (kept != nullptr) {
         RST_REQUIRE(aligned16(kept), "bf16 block: the buffer for the kept attention must be 16-byte aligned");
         Carve ck(kept);
         keep = kept_carve(d, ck);
         b.attn = keep.attn; b.mfold = keep.mfold;
     }
-    bf16_t* t = b.buf1; bf16_t* qkv = b.buf2; bf16_t* u = b.buf1; bf16_t* gbuf = b.buf2;
+    if (saved != nullptr) {
+        RST_REQUIRE(aligned16(saved), "bf16 block: the buffer for the saved activations must be 16-byte aligned");
+        RST_REQUIRE(y != x, "bf16 block: a forward pass that saves its activations cannot run in place");
+        Carve cs(saved);
+        sv = saved_carve(d, cs);
+        keep = sv.k;
+        b.attn = keep.attn; b.mfold = keep.mfold;
+        kept = saved;
+    }
+    bf16_t* t = saved ? sv.t : b.buf1; bf16_t* qkv = saved ? sv.qkv : b.buf2;
+    bf16_t* u = saved ? sv.u : b.buf1; bf16_t* gbuf = saved ? sv.g : b.buf2;
+    bf16_t* x1 = saved ? sv.x1 : y;
     const int64_t cn = (int64_t)C * N;
 
     // ---- MDTA (model/Restromer.py:128-150) ----
     // The fused 1x1 + depthwise kernel (pwdw_ring_kernel: the intermediate stays in LDS) takes both pairs wherever it
     // supports the shape (at most 96 input channels).  RST_BF16_FUSE=0: never (tests, A/B runs)
     static const int fuse_mode = getenv("RST_BF16_FUSE") != nullptr ? atoi(getenv("RST_BF16_FUSE")) : 1;
-    const bool fuse = fuse_mode > 0 && pwdw_pk_supported(C / 8, d->W, d->H);
+    const bool fuse = fuse_mode > 0 && saved == nullptr && pwdw_pk_supported(C / 8, d->W, d->H);
     const bool fuse_gate = fuse;
     if (fuse) {
         PwDwPk f{};
@@ -249,7 +282,7 @@ static int pk_block_fwd(const rst_block_desc* d, const rst_block_params* p, cons
     if (cb) RST_TRY(pk_prep_sc_launch(p->proj_weight, C, nullptr, nullptr, p->proj_bias, C, C, big, big, b.wattn.npos,
                                       b.wattn.s, b.wattn.c, stream));
     {
-        GemmPk g = pk_gemm_args(b.wattn, qkv + 2 * cn, 3 * cn, y, cn, B, N);
+        GemmPk g = pk_gemm_args(b.wattn, qkv + 2 * cn, 3 * cn, x1, cn, B, N);
         g.a_bs = (int64_t)b.wattn.frag_elems() / 8;
         g.R = x; g.r_bs = cn;
         g.ln_c = cb ? b.wattn.c : nullptr;
@@ -258,22 +291,30 @@ static int pk_block_fwd(const rst_block_desc* d, const rst_block_params* p, cons
     // ---- GDFN (model/Restromer.py:99-104) ----
     if (fuse_gate) {
         PwDwPk f{};
-        f.A = b.wpin.frag; f.X = y; f.x_bs = cn; f.Y = gbuf; f.y_bs = (int64_t)Hp * N;
+        f.A = b.wpin.frag; f.X = x1; f.x_bs = cn; f.Y = gbuf; f.y_bs = (int64_t)Hp * N;
         f.ln_s = b.wpin.s; f.ln_c = b.wpin.c; f.ln_mode = ln_mode; f.dww = b.dw_ffn;
         f.K = C; f.Kb = C / 8; f.Mb = 2 * Hp / 8; f.B = B; f.H = d->H; f.W = d->W; f.gate = 1;
         RST_TRY(pwdw_pk_launch(f, stream));
     } else {
-        GemmPk g = pk_gemm_args(b.wpin, y, cn, u, (int64_t)2 * Hp * N, B, N);
+        GemmPk g = pk_gemm_args(b.wpin, x1, cn, u, (int64_t)2 * Hp * N, B, N);
         g.ln_mode = ln_mode; g.ln_s = b.wpin.s; g.ln_c = b.wpin.c;
         RST_TRY(gemm_pk_launch(g, stream));
         DwPk a{};
-        a.x = u; a.x_bs = (int64_t)2 * Hp * N; a.wp = b.dw_ffn; a.y = gbuf; a.y_bs = (int64_t)Hp * N;
-        a.B = B; a.Cb = 2 * Hp / 8; a.H = d->H; a.W = d->W; a.gate = 1;
-        RST_TRY(dw_pk_launch(a, stream));
+        a.x = u; a.x_bs = (int64_t)2 * Hp * N; a.wp = b.dw_ffn;
+        a.B = B; a.Cb = 2 * Hp / 8; a.H = d->H; a.W = d->W;
+        if (saved != nullptr) {
+            // the backward pass wants both halves before the gate as well as their product
+            a.y = sv.d; a.y_bs = (int64_t)2 * Hp * N; a.gate = 0;
+            RST_TRY(dw_pk_launch(a, stream));
+            RST_TRY(gate_fwd_pk_launch(sv.d, gbuf, B, Hp / 8, N, stream));
+        } else {
+            a.y = gbuf; a.y_bs = (int64_t)Hp * N; a.gate = 1;
+            RST_TRY(dw_pk_launch(a, stream));
+        }
     }
     {
         GemmPk g = pk_gemm_args(b.wpout, gbuf, (int64_t)Hp * N, y, cn, B, N);
-        g.R = y; g.r_bs = cn;
+        g.R = x1; g.r_bs = cn;
         g.ln_c = cb ? b.wpout.c : nullptr;
         RST_TRY(gemm_pk_launch(g, stream));
     }
@@ -343,14 +384,16 @@ WgradPk pk_wgrad_shape(int Ab, int Bb, int B, int64_t N, bool with_rowsum) {
     return g;
 }
 
-void pk_bwd_carve(const rst_block_desc* d, Carve& cv, PkBwdBufs& b) {
+void pk_bwd_carve(const rst_block_desc* d, Carve& cv, PkBwdBufs& b, bool own_acts = true) {
     const int C = d->C, Hd = d->hidden, Hp = pad8(Hd), heads = d->heads, c = C / heads, B = d->B;
     const int64_t N = (int64_t)d->H * d->W;
     const size_t bn = (size_t)B * N;
     pk_block_carve_prepared(d, cv, b.f);
     pk_block_carve(d, cv, b.f);                      // (its buf1 / buf2 are not used here)
-    b.t = cv.halves(bn * 3 * C); b.qkv = cv.halves(bn * 3 * C); b.x1 = cv.halves(bn * C);
-    b.u = cv.halves(bn * 2 * Hp); b.d = cv.halves(bn * 2 * Hp); b.g = cv.halves(bn * Hp);
+    if (own_acts) {
+        b.t = cv.halves(bn * 3 * C); b.qkv = cv.halves(bn * 3 * C); b.x1 = cv.halves(bn * C);
+        b.u = cv.halves(bn * 2 * Hp); b.d = cv.halves(bn * 2 * Hp); b.g = cv.halves(bn * Hp);
+    }
     b.dg = cv.halves(bn * Hp); b.dd = cv.halves(bn * 2 * Hp); b.du = cv.halves(bn * 2 * Hp);
     b.xh = cv.halves(bn * C); b.dn = cv.halves(bn * C); b.dx1 = cv.halves(bn * C);
     b.dqkv = cv.halves(bn * 3 * C); b.dt = cv.halves(bn * 3 * C);
@@ -385,9 +428,9 @@ void pk_bwd_carve(const rst_block_desc* d, Carve& cv, PkBwdBufs& b) {
     b.dw_part = cv.floats(b.dw_floats);
     b.dw_red = cv.floats((size_t)(wmax / 8) * 80);
 }
-size_t pk_block_bwd_ws_bytes(const rst_block_desc* d) {
+size_t pk_block_bwd_ws_bytes(const rst_block_desc* d, bool own_acts = true) {
     Carve cv(nullptr); PkBwdBufs b{};
-    pk_bwd_carve(d, cv, b);
+    pk_bwd_carve(d, cv, b, own_acts);
     return cv.total();
 }
 
@@ -469,15 +512,18 @@ int side_stream_for_current_device(SideStream** out) {
 }  // namespace
 
 static int pk_block_bwd(const rst_block_desc* d, const rst_block_params* p, const void* prepared, const bf16_t* x, const bf16_t* dy,
-                        bf16_t* dx, rst_block_grads* gr, const void* kept, void* ws, size_t ws_bytes, hipStream_t stream) {
+                        bf16_t* dx, rst_block_grads* gr, const void* kept, const void* saved, void* ws, size_t ws_bytes,
+                        hipStream_t stream) {
     RST_REQUIRE(x && dy && dx && p && gr, "bf16 block backward: null operand");
     RST_REQUIRE(gr->norm1_weight && gr->norm2_weight && gr->temperature && gr->qkv_weight && gr->qkv_dw_weight && gr->proj_weight &&
                 gr->pin_weight && gr->ffn_dw_weight && gr->pout_weight, "bf16 block backward: null gradient buffer");
     RST_REQUIRE(!d->ln_with_bias || (gr->norm1_bias && gr->norm2_bias), "bf16 block backward: null LayerNorm bias gradient buffer");
     RST_REQUIRE(!d->conv_bias || (gr->qkv_bias && gr->qkv_dw_bias && gr->proj_bias && gr->pin_bias && gr->ffn_dw_bias && gr->pout_bias),
                 "bf16 block backward: null bias gradient buffer");
-    if (ws == nullptr || ws_bytes < pk_block_bwd_ws_bytes(d))
-        return fail(RST_ERR_WORKSPACE, "bf16 block backward: workspace %zu < %zu bytes", ws_bytes, pk_block_bwd_ws_bytes(d));
+    RST_REQUIRE(kept == nullptr || saved == nullptr, "bf16 block backward: either the kept attention or the saved activations");
+    const bool own_acts = saved == nullptr;
+    if (ws == nullptr || ws_bytes < pk_block_bwd_ws_bytes(d, own_acts))
+        return fail(RST_ERR_WORKSPACE, "bf16 block backward: workspace %zu < %zu bytes", ws_bytes, pk_block_bwd_ws_bytes(d, own_acts));
     const int C = d->C, Hd = d->hidden, Hp = pad8(Hd), heads = d->heads, c = C / heads, B = d->B;
     const int64_t N = (int64_t)d->H * d->W;
     const int64_t cn = (int64_t)C * N, hn = (int64_t)Hp * N;
@@ -485,7 +531,7 @@ static int pk_block_bwd(const rst_block_desc* d, const rst_block_params* p, cons
     const int wb = d->ln_with_bias ? 1 : 0;
     const int ln_mode = wb ? 1 : 2;
     Carve cv(ws); PkBwdBufs b{};
-    pk_bwd_carve(d, cv, b);
+    pk_bwd_carve(d, cv, b, own_acts);
     if (prepared != nullptr) {
         Carve cp(const_cast<void*>(prepared));
         pk_block_carve_prepared(d, cp, b.f);             // the forward pass's prepared weights: nothing changed since
@@ -498,6 +544,14 @@ static int pk_block_bwd(const rst_block_desc* d, const rst_block_params* p, cons
         Carve ck(const_cast<void*>(kept));
         const KeptAttn k = kept_carve(d, ck);
         b.f.attn = k.attn; b.ghat = k.ghat; b.nq = k.nq; b.nk = k.nk; b.f.mfold = k.mfold;
+    }
+    if (saved != nullptr) {
+        // the forward pass saved everything this pass reads: nothing is evaluated again
+        RST_REQUIRE(aligned16(saved), "bf16 block backward: the saved activations must be 16-byte aligned");
+        Carve cs(const_cast<void*>(saved));
+        const SavedActs sv = saved_carve(d, cs);
+        b.f.attn = sv.k.attn; b.ghat = sv.k.ghat; b.nq = sv.k.nq; b.nk = sv.k.nk; b.f.mfold = sv.k.mfold;
+        b.t = sv.t; b.qkv = sv.qkv; b.x1 = sv.x1; b.u = sv.u; b.d = sv.d; b.g = sv.g;
     }
 
     SideStream* sd = nullptr;
@@ -517,6 +571,7 @@ static int pk_block_bwd(const rst_block_desc* d, const rst_block_params* p, cons
     };
     auto body = [&]() -> int {
     // ---------------- forward again, everything kept ----------------
+    if (saved == nullptr) {
     {
         GemmPk g = pk_gemm_args(b.f.wqkv, x, cn, b.t, 3 * cn, B, N);
         g.ln_mode = ln_mode; g.ln_s = b.f.wqkv.s; g.ln_c = b.f.wqkv.c;
@@ -561,6 +616,7 @@ static int pk_block_bwd(const rst_block_desc* d, const rst_block_params* p, cons
         a.B = B; a.Cb = 2 * Hp / 8; a.H = d->H; a.W = d->W; a.gate = 0;
         RST_TRY(dw_pk_launch(a, stream));
     }
+    }
 
     // ---------------- weights of the data gradients ----------------
     {
@@ -586,7 +642,7 @@ static int pk_block_bwd(const rst_block_desc* d, const rst_block_params* p, cons
     // Four hand-overs to the side stream per block, not one per operand: recording an event and waiting for it cost
     // the host about as much as a kernel launch, and the step must not become bound by the host's queueing.
     RST_TRY(fork());                                 // d (and x1, for the statistics below) are there
-    RST_TRY(gate_fwd_pk_launch(b.d, b.g, B, Hp / 8, N, side));     // g: only project_out's weight gradient reads it
+    if (saved == nullptr) RST_TRY(gate_fwd_pk_launch(b.d, b.g, B, Hp / 8, N, side));     // g: only project_out's weight gradient reads it
     RST_TRY(pk_wgrad(dy, cn, C / 8, b.g, hn, Hp / 8, B, N, false, cb, b.red, b.part, b.part_floats, side));
     RST_TRY(crop2d_launch(b.red, Hp, gr->pout_weight, C, Hd, side));
     if (cb) RST_HIP(hipMemcpyAsync(gr->pout_bias, b.red + (size_t)C * Hp, sizeof(float) * C, hipMemcpyDeviceToDevice, side));
@@ -705,14 +761,14 @@ int rst_bf16_block_bwd(const rst_block_desc* desc, const rst_block_params* param
                        void* stream) {
     RST_TRY(check_pk_desc(desc));
     return pk_block_bwd(desc, params, prepared, static_cast<const bf16_t*>(x_packed), static_cast<const bf16_t*>(dy_packed),
-                        static_cast<bf16_t*>(dx_packed), grads, nullptr, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+                        static_cast<bf16_t*>(dx_packed), grads, nullptr, nullptr, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 size_t rst_bf16_block_kept_bytes(const rst_block_desc* desc) { return check_pk_desc(desc) == RST_OK ? pk_block_kept_bytes(desc) : 0; }
 int rst_bf16_block_fwd_keep(const rst_block_desc* d, const rst_block_params* p, const void* prepared, const void* x_packed, void* y_packed,
                             void* kept, void* workspace, size_t workspace_bytes, void* stream) {
     RST_TRY(check_pk_desc(d));
     RST_REQUIRE(kept != nullptr, "bf16 block: null buffer for the kept attention");
-    return pk_block_fwd(d, p, prepared, static_cast<const bf16_t*>(x_packed), static_cast<bf16_t*>(y_packed), kept, workspace,
+    return pk_block_fwd(d, p, prepared, static_cast<const bf16_t*>(x_packed), static_cast<bf16_t*>(y_packed), kept, nullptr, workspace,
                         workspace_bytes, static_cast<hipStream_t>(stream));
 }
 int rst_bf16_block_bwd_kept(const rst_block_desc* desc, const rst_block_params* params, const void* prepared, const void* x_packed,
@@ -721,7 +777,26 @@ int rst_bf16_block_bwd_kept(const rst_block_desc* desc, const rst_block_params* 
     RST_TRY(check_pk_desc(desc));
     RST_REQUIRE(kept != nullptr, "bf16 block backward: null kept attention");
     return pk_block_bwd(desc, params, prepared, static_cast<const bf16_t*>(x_packed), static_cast<const bf16_t*>(dy_packed),
-                        static_cast<bf16_t*>(dx_packed), grads, kept, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+                        static_cast<bf16_t*>(dx_packed), grads, kept, nullptr, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+size_t rst_bf16_block_saved_bytes(const rst_block_desc* desc) { return check_pk_desc(desc) == RST_OK ? pk_block_saved_bytes(desc) : 0; }
+size_t rst_bf16_block_bwd_saved_workspace_bytes(const rst_block_desc* desc) {
+    return check_pk_desc(desc) == RST_OK ? pk_block_bwd_ws_bytes(desc, false) : 0;
+}
+int rst_bf16_block_fwd_save(const rst_block_desc* d, const rst_block_params* p, const void* prepared, const void* x_packed, void* y_packed,
+                            void* saved, void* workspace, size_t workspace_bytes, void* stream) {
+    RST_TRY(check_pk_desc(d));
+    RST_REQUIRE(saved != nullptr, "bf16 block: null buffer for the saved activations");
+    return pk_block_fwd(d, p, prepared, static_cast<const bf16_t*>(x_packed), static_cast<bf16_t*>(y_packed), nullptr, saved, workspace,
+                        workspace_bytes, static_cast<hipStream_t>(stream));
+}
+int rst_bf16_block_bwd_saved(const rst_block_desc* desc, const rst_block_params* params, const void* prepared, const void* x_packed,
+                             const void* dy_packed, void* dx_packed, rst_block_grads* grads, const void* saved, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+    RST_TRY(check_pk_desc(desc));
+    RST_REQUIRE(saved != nullptr, "bf16 block backward: null saved activations");
+    return pk_block_bwd(desc, params, prepared, static_cast<const bf16_t*>(x_packed), static_cast<const bf16_t*>(dy_packed),
+                        static_cast<bf16_t*>(dx_packed), grads, nullptr, saved, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 int rst_bf16_to_channels_last(const void* x_packed, void* y_nhwc, int32_t B, int32_t C, int64_t N, void* stream) {
@@ -812,7 +887,7 @@ int rst_bf16_block_prepare(const rst_block_desc* d, const rst_block_params* p, v
 int rst_bf16_block_fwd(const rst_block_desc* d, const rst_block_params* p, const void* prepared, const void* x_packed, void* y_packed,
                        void* workspace, size_t workspace_bytes, void* stream) {
     RST_TRY(check_pk_desc(d));
-    return pk_block_fwd(d, p, prepared, static_cast<const bf16_t*>(x_packed), static_cast<bf16_t*>(y_packed), nullptr, workspace,
+    return pk_block_fwd(d, p, prepared, static_cast<const bf16_t*>(x_packed), static_cast<bf16_t*>(y_packed), nullptr, nullptr, workspace,
                         workspace_bytes, static_cast<hipStream_t>(stream));
 }
 

@@ -173,3 +173,72 @@ def test_block_backward_with_kept_attention(C, heads, hidden, H, W, ln_bias, con
         assert _cos(g_k[name], ref) > 0.995 and float((g_k[name] - ref).norm() / ref.norm()) < 0.1, name
     with pytest.raises(RuntimeError):
         bf16.block_backward(bf16.pack(x), bf16.pack(dy), heads, hidden, params, kept_attn=kept[:16])
+
+
+@pytest.mark.parametrize("C,heads,hidden,H,W,ln_bias,conv_bias", CASES)
+def test_block_backward_with_saved_activations(C, heads, hidden, H, W, ln_bias, conv_bias):
+    """rst_bf16_block_fwd_save + rst_bf16_block_bwd_saved: the forward pass leaves every intermediate the backward pass
+    reads, the backward pass evaluates nothing again.  The forward pass runs the same unfused kernels the recomputing
+    backward runs, so the gradients equal those of rst_bf16_block_bwd bit for bit; the output agrees with the
+    inference forward to bf16 accuracy."""
+    from superresolution_amd import bf16
+    from superresolution_amd.model.Restromer import TransformerBlock
+    torch.manual_seed(C + hidden + H)
+    blk = TransformerBlock(C, heads, (hidden + 0.5) / C, conv_bias, "WithBias" if ln_bias else "BiasFree").cuda()
+    with torch.no_grad():
+        for n, p in blk.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.3 * torch.randn_like(p))
+    x = torch.randn(2, C, H, W, device="cuda").bfloat16()
+    dy = torch.randn(2, C, H, W, device="cuda").bfloat16()
+    params = blk._params()
+    xp = bf16.pack(x)
+    y_save, saved = bf16.block_forward_save(xp, heads, hidden, params)
+    assert torch.equal(xp.data, bf16.pack(x).data)                      # the input is left alone
+    y_plain = bf16.block_(bf16.pack(x), heads, hidden, params)
+    a, b = bf16.unpack(y_save, torch.float32), bf16.unpack(y_plain, torch.float32)
+    # (not bit for bit even where nothing is fused: the gate reads the depthwise result after its rounding to bf16 here)
+    assert float((a - b).norm() / b.norm()) < 1e-2                            # measured <= 2.5e-3
+    for _ in range(2):                                                        # the saved buffer is only read
+        dxp_s, g_s = bf16.block_backward(bf16.pack(x), bf16.pack(dy), heads, hidden, params, saved=saved)
+        dxp_r, g_r = bf16.block_backward(bf16.pack(x), bf16.pack(dy), heads, hidden, params)
+        assert torch.equal(dxp_s.data, dxp_r.data)
+        for name, ref in g_r.items():
+            if ref is None:
+                assert g_s[name] is None
+            else:
+                assert torch.equal(g_s[name], ref), name
+    with pytest.raises(RuntimeError):
+        bf16.block_backward(bf16.pack(x), bf16.pack(dy), heads, hidden, params, saved=saved[:64])
+    with pytest.raises(RuntimeError):
+        bf16.block_backward(bf16.pack(x), bf16.pack(dy), heads, hidden, params, saved=saved, kept_attn=saved)
+
+
+def test_stage_saves_or_recomputes(monkeypatch):
+    """bf16.stage: saved activations (default while they fit), kept attention (RST_BF16_SAVE=0) and input only
+    (RST_BF16_KEEP_ATTN=0 as well) give the same gradients to bf16 accuracy."""
+    from superresolution_amd import bf16
+    from superresolution_amd.model.Restromer import TransformerBlock
+    torch.manual_seed(9)
+    blocks = torch.nn.Sequential(*[TransformerBlock(48, 1, 1.25, False, "BiasFree") for _ in range(2)]).cuda()
+    x = torch.randn(2, 48, 16, 16, device="cuda").bfloat16()
+    r = torch.randn(2, 48, 16, 16, device="cuda")
+    res = {}
+    for name, env in (("saved", {}), ("forced", {"RST_BF16_SAVE": "1"}), ("kept", {"RST_BF16_SAVE": "0"}),
+                      ("input", {"RST_BF16_SAVE": "0", "RST_BF16_KEEP_ATTN": "0"})):
+        for k in ("RST_BF16_SAVE", "RST_BF16_KEEP_ATTN"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for p in blocks.parameters():
+            p.grad = None
+        xa = x.clone().requires_grad_(True)
+        y = bf16.stage(xa, blocks)
+        (y.float() * r).sum().backward()
+        res[name] = (y.detach().float().clone(), xa.grad.float().clone(), {k: p.grad.clone() for k, p in blocks.named_parameters()})
+    assert torch.equal(res["saved"][1], res["forced"][1])
+    for name in ("kept", "input"):
+        assert float((res[name][0] - res["saved"][0]).norm() / res["saved"][0].norm()) < 1e-2
+        assert _cos(res[name][1], res["saved"][1]) > 0.999
+        for k in res["saved"][2]:
+            assert _cos(res[name][2][k], res["saved"][2][k]) > 0.995, (name, k)
