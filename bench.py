@@ -38,7 +38,20 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3    # MI355X v_mfma_f32_* dense peak
+PEAK_F16_MATRIX_TFLOPS = 2500.0    # MI355X v_mfma_f32_16x16x32_{f16,bf16} dense peak
 PEAK_HBM_GBS = 8000.0              # MI355X HBM3E peak
+
+
+def matrix_peak_tflops(name: str) -> float:
+    """The matrix-pipe roof a kernel class is held against: the exact-fp32 classes run v_mfma_f32_16x16x4_f32; a
+    split-f16 class (*_f16s*) spends three f16 instructions per fp32 product, so its roof in fp32-equivalent flops is
+    a third of the f16 peak; the packed bf16 classes (pk_*) run one bf16 instruction per product."""
+    if "f16s" in name:
+        return PEAK_F16_MATRIX_TFLOPS / 3.0
+    if name.startswith("pk_") or name.endswith("_f16"):
+        return PEAK_F16_MATRIX_TFLOPS
+    return PEAK_FP32_MATRIX_TFLOPS
+
 MFMA_KERNELS = {"gemm_nn", "gemm_nn_ln", "gemm_nt_splitk", "pwdw", "pwdw_gate"}
 
 
@@ -190,7 +203,9 @@ def roofline_from(prof, traffic_of=lambda name: None):
                  "traffic": traffic_of(name), "algorithmic_bytes_per_launch": round(k["bytes"] / k["launches"])})
     total = sum(v["ms"] for v in prof.values())
     breakdown = {n: {"ms": round(v["ms"], 3), "share": round(v["ms"] / total, 3),
-                     "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1), "TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
+                     "GB/s": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1), "TFLOP/s": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                     "frac_hbm": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 3),
+                     "frac_matrix": round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / matrix_peak_tflops(n), 3)}
                  for n, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
     return roof, breakdown, total
 

@@ -10,7 +10,8 @@ import os
 from ctypes import POINTER, c_char_p, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librestormer_hip.so")
+# (RST_LIB_PATH: another build of the same library, for A/B timing of kernel variants)
+LIB_PATH = os.environ.get("RST_LIB_PATH") or os.path.join(_HERE, "librestormer_hip.so")
 
 ABI_VERSION = 1
 

@@ -32,6 +32,12 @@ typedef __attribute__((address_space(3))) void* ws_lptr;
 typedef float ws_f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned ws_u32x4 __attribute__((ext_vector_type(4)));
 
+// Timing experiments only (results are wrong): -DWS_ABL=1 vector waves without the depthwise arithmetic and stores,
+// 2 also without picking the row up, 3 matrix waves without MFMAs, 4 also without the conversion, 5 no stores
+#ifndef WS_ABL
+#define WS_ABL 0
+#endif
+
 constexpr int WS_T = 4;                  // MFMA tiles per strip row
 constexpr int WS_WT = 16 * WS_T;         // strip width
 constexpr int WS_CPR = 20;               // 16-byte pieces per channel row in LDS (4 px halo + 64 + 4 px halo, padded)
@@ -85,8 +91,16 @@ __device__ __forceinline__ void ws_static_for(F&& f) {
 // Ablations at 16 x 96 x 256 x 256 (plain / gated, us): full kernel 679 / 496; DMA stream and barriers alone 238 / 170
 // (the input strip is read once per channel group, 3x / 2x: 1.2 GB at ~5 TB/s); matrix side without the vector
 // waves' work 507 / 355; vector side without conversion and MFMAs 591 / 350; without stores 579 / 487: neither
-// side nor memory is the single bound -- three barrier-separated phases per row of dependent LDS round trips on
-// twelve waves are.
+// side nor memory is the single bound.
+// With every LDS read of a phase issued behind its barrier (one round trip per phase instead of six on either side)
+// the plain kernel went from 7.17 to 6.91 ms per step of 16 x 3 x 256^2 (20 launches), so the round trips were not
+// the bound either.  The same step with parts compiled out (-DWS_ABL=n, ms for the 20 launches): no stores 5.27; vector
+// waves without arithmetic and stores 5.40, without the pick-up as well 5.38; matrix waves without MFMAs and
+// conversion 6.20.  What moves the time is memory: a block owns 1/256 of ~4.7 TB/s = 8.7 bytes per cycle, and a row
+// of a block moves 24.6 KB out and 15 KB in from HBM (the strip is fetched 1.83 times for the three channel groups)
+// = 4 550 cycles of the 7 000 a row takes.  Tried without gain: non-temporal stores (7.18; the Gram kernel behind it
+// gains what this one loses), ten ring stages (6.96), half of the depthwise arithmetic in the pick-up phase (7.07),
+// no packed fp32 arithmetic (7.04).
 template <int KS, int NM, bool GATE, bool F16S = false>
 __global__ void __launch_bounds__(NM * 128) __attribute__((amdgpu_waves_per_eu(GATE ? 4 : 3, GATE ? 4 : 3)))
 pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
@@ -169,19 +183,41 @@ pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
             const int ccol = slab < T ? 4 + 16 * slab + lm : (lm == 0 ? 3 : 4 + WT);
             const bool cvalid = slab < T || lm < 2;
             float cs1 = 0.f, cs2 = 0.f;                  // LayerNorm sums of this lane's pixel column over its channel share
-            auto convert = [&](int stage, int buf) __attribute__((always_inline)) {
+            // Every LDS read of a phase is issued right behind its barrier -- the ten operand fragments of the chunk
+            // to multiply, then the eight ring values of the chunk to convert -- and waited for by count as it is
+            // needed (LDS returns in order): one exposed LDS round trip per phase instead of six.  (Left to the
+            // compiler the reads went out two at a time, each pair followed by a full wait: 2 800 cycles per phase,
+            // of which the matrix pipe worked 240.)
+            ws_h8 ah[T + 1], al[T + 1];
+            ws_f32x2 cv[4];
+            auto fetch_phase = [&](int stage, int buf_mul) __attribute__((always_inline)) {
+                const unsigned ia = (unsigned)(uintptr_t)(ws_lptr)(img + buf_mul * 5 * 2 * 64 + lane);
+                ws_static_for<0, T + 1>([&](auto Jc) {
+                    constexpr int j = decltype(Jc)::value;
+                    ws_h8 &rh = ah[j], &rl = al[j];                 // (an asm operand cannot name a captured variable itself)
+                    const unsigned addr = ia;
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rh) : "v"(addr), "n"((j * 2 + 0) * 1024));
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(rl) : "v"(addr), "n"((j * 2 + 1) * 1024));
+                });
+                const unsigned ca = (unsigned)(uintptr_t)(ws_lptr)(ring + stage * XCH + kk * ROWF + ccol);
+                ws_static_for<0, 4>([&](auto Pc) {
+                    constexpr int p = decltype(Pc)::value;         // channels kk + 8 p and kk + 8 p + 4 of the chunk
+                    ws_f32x2& r = cv[p];
+                    const unsigned addr = ca;
+                    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(r) : "v"(addr), "n"(10 * p), "n"(10 * p + 5));
+                });
+            };
+            static_assert(ROWF * 4 * 4 == 5 * 256, "ds_read2st64 offsets above assume 320 floats between the channels of a lane");
+            auto convert = [&](int buf) __attribute__((always_inline)) {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(cv[0]), "+v"(cv[1]), "+v"(cv[2]), "+v"(cv[3]));
                 if (slab <= T) {
-                    const float* Xs = ring + stage * XCH + kk * ROWF + ccol;
-                    float v[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = Xs[4 * i * ROWF];
                     ws_h8 hi, lo;
                     typedef _Float16 ws_h2 __attribute__((ext_vector_type(2)));
                     ws_f32x2 p1 = {0.f, 0.f}, p2 = {0.f, 0.f};
 #pragma unroll
                     for (int i = 0; i < 8; i += 2) {
                         // two channels at a time: packed conversions, the residual (x - hi) * 2048 as fma(hi, -2048, 2048 x)
-                        const ws_f32x2 x = {cvalid ? v[i] : 0.f, cvalid ? v[i + 1] : 0.f};
+                        const ws_f32x2 x = {cvalid ? cv[i / 2][0] : 0.f, cvalid ? cv[i / 2][1] : 0.f};
                         const ws_h2 h = __builtin_convertvector(x, ws_h2);
                         const ws_f32x2 sc = x * 2048.f;
                         const ws_f32x2 r2 = {fmaf((float)h[0], -2048.f, sc[0]), fmaf((float)h[1], -2048.f, sc[1])};
@@ -250,15 +286,19 @@ pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
                     // chunk q landed for this wave (two newer chunks may be in flight), then for everyone
                     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" :: "n"(NEWER_M) : "memory");
                     issue();
-                    if (q > 0 && q <= nq) {
-                        const ws_h8* im = img + ((q - 1) & 1) * 5 * 2 * 64 + lane;
+                    fetch_phase(stage_c, (q + 1) & 1);
+                    if (WS_ABL != 3 && WS_ABL != 4 && q > 0 && q <= nq) {
+                        ws_static_for<0, T + 1>([&](auto Jc) {
+                            constexpr int j = decltype(Jc)::value;
+                            // fragments 0 .. j are there; the younger ones and the four conversion reads may be in flight
+                            ws_h8 &rh = ah[j], &rl = al[j];
+                            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(rh), "+v"(rl) : "n"(4 + 2 * (T - j)));
+                            acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[j], whi[cw], acc1[j], 0, 0, 0);
+                            acc2[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[j], wlo[cw], acc2[j], 0, 0, 0);
+                        });
 #pragma unroll
-                        for (int j = 0; j <= T; ++j) {
-                            const ws_h8 ah = im[(j * 2 + 0) * 64], al = im[(j * 2 + 1) * 64];
-                            acc1[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, whi[cw], acc1[j], 0, 0, 0);
-                            acc2[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wlo[cw], acc2[j], 0, 0, 0);
-                            acc2[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, whi[cw], acc2[j], 0, 0, 0);
-                        }
+                        for (int j = 0; j <= T; ++j)
+                            acc2[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[j], whi[cw], acc2[j], 0, 0, 0);
                     }
                     if (c == 0 && rr > 0) {
                         // row rr - 1 is complete: hand it over (the vector waves read it in the next phase)
@@ -274,8 +314,8 @@ pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
 #pragma unroll
                         for (int j = 0; j <= T; ++j) { acc1[j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
                     }
-                    if (q < nq) {
-                        convert(stage_c, q & 1);
+                    if (WS_ABL != 4 && q < nq) {
+                        convert(q & 1);
                         if (c == NC - 1) {
                             // per-pixel LayerNorm constants of row ra + rr, read by the vector waves in the next row's
                             // second phase (two barriers from here)
@@ -434,7 +474,7 @@ pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
     auto store_tile = [&](const f32x4& v, int row, int j, bool rowok) __attribute__((always_inline)) {
         const int px = px0 + 16 * j + 4 * kk;
         const unsigned vo = (rowok && px < W) ? yoff + (unsigned)(row * W * 4) + 64u * j : 0x80000000u;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ws_u32x4, v), yrsrc, vo, 0, 0);
+        if (WS_ABL != 5) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ws_u32x4, v), yrsrc, vo, 0, 0);
     };
 
     f32x4 Pst[NH][TV], Qst[NH][TV], tp[NH][TV];
@@ -518,66 +558,135 @@ pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
                 }
             }
 
-            if (c == HC && have_prev) {
-                // ---- raw row out of the hand-off buffer; LayerNorm constants, bias, zero padding ----
-                const float* sm = statm + (prow & 1) * ROWF;
-                const float* sr = statr + (prow & 1) * ROWF;
-#pragma unroll
-                for (int h = 0; h < NH; ++h) {
-                    const int hs = GATE ? h * PAIRS + pair : slab;              // hand-off slot of this half
-                    const f32x4* hd = reinterpret_cast<const f32x4*>(hand) + hs * T * 64;
-                    const float* hh = halo + hs * 2 * 64 + lm;                  // + 16 * k: the k share
+            if (WS_ABL != 2 && c == HC && have_prev) {
+                if constexpr (F16S && !GATE) {
+                    // ---- raw row out of the hand-off buffer; LayerNorm constants, bias, zero padding ----
+                    // Every LDS read of the phase goes out first and nothing is computed until they are all under way
+                    // (one LDS round trip; in source order the compiler waited after each group of reads: six).
+                    const float* sm = statm + (prow & 1) * ROWF;
+                    const float* sr = statr + (prow & 1) * ROWF;
                     // the pixel left of the first tile and right of the last one: a halo column of the strip, or
                     // (GATE) a pixel of the other half of the strip, raw in the hand-off buffer
-                    float outl, outr;
-                    if (tv0 == 0) {
-                        float hlp = 0.f;
+                    const int colL = tv0 == 0 ? 3 : 4 + 16 * tv0 - 1;
+                    const int colR = tv0 + TV == T ? 4 + WT : 4 + 16 * (tv0 + TV);
+                    const float smL = sm[colL], srL = sr[colL], smR = sm[colR], srR = sr[colR];
+                    float hlq[NH][4], hrq[NH][4], nbl[NH], nbr[NH];
+                    f32x4 rawt[NH][TV], tco[TV], rstd[TV];
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) hlp += hh[16 * k];
-                        outl = in_l ? fmaf(sr[3], fmaf(sm[3], lns[h], hlp), lnc[h]) : 0.f;
-                    } else {
-                        const int colx = 4 + 16 * tv0 - 1;
-                        const float raw = reinterpret_cast<const float*>(hd + (tv0 - 1) * 64 + 48 + lm)[3];
-                        outl = px0 + colx - 4 < W ? fmaf(sr[colx], fmaf(sm[colx], lns[h], raw), lnc[h]) : 0.f;
-                    }
-                    if (tv0 + TV == T) {
-                        float hrp = 0.f;
+                    for (int h = 0; h < NH; ++h) {
+                        const int hs = GATE ? h * PAIRS + pair : slab;              // hand-off slot of this half
+                        const f32x4* hd = reinterpret_cast<const f32x4*>(hand) + hs * T * 64;
+                        const float* hh = halo + hs * 2 * 64 + lm;                  // + 16 * k: the k share
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) hrp += hh[64 + 16 * k];
-                        outr = in_r ? fmaf(sr[4 + WT], fmaf(sm[4 + WT], lns[h], hrp), lnc[h]) : 0.f;
-                    } else {
-                        const int colx = 4 + 16 * (tv0 + TV);
-                        const float raw = reinterpret_cast<const float*>(hd + (tv0 + TV) * 64 + lm)[0];
-                        outr = px0 + colx - 4 < W ? fmaf(sr[colx], fmaf(sm[colx], lns[h], raw), lnc[h]) : 0.f;
+                        for (int k = 0; k < 4; ++k) { hlq[h][k] = hh[16 * k]; hrq[h][k] = hh[64 + 16 * k]; }
+                        if constexpr (GATE) {
+                            nbl[h] = reinterpret_cast<const float*>(hd + (tv0 > 0 ? tv0 - 1 : 0) * 64 + 48 + lm)[3];
+                            nbr[h] = reinterpret_cast<const float*>(hd + (tv0 + TV < T ? tv0 + TV : T - 1) * 64 + lm)[0];
+                        } else {
+                            nbl[h] = 0.f; nbr[h] = 0.f;
+                        }
+#pragma unroll
+                        for (int j = 0; j < TV; ++j) rawt[h][j] = hd[(tv0 + j) * 64 + lane];
                     }
 #pragma unroll
                     for (int j = 0; j < TV; ++j) {
-                        const int jt = tv0 + j;
-                        const f32x4 raw = hd[jt * 64 + lane];
-                        const f32x4 tco = *reinterpret_cast<const f32x4*>(&sm[4 + 16 * jt + 4 * kk]);
-                        const f32x4 rstd = *reinterpret_cast<const f32x4*>(&sr[4 + 16 * jt + 4 * kk]);
-                        const bool live = px0 + 16 * jt + 4 * kk < W;
+                        tco[j] = *reinterpret_cast<const f32x4*>(&sm[4 + 16 * (tv0 + j) + 4 * kk]);
+                        rstd[j] = *reinterpret_cast<const f32x4*>(&sr[4 + 16 * (tv0 + j) + 4 * kk]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float v = fmaf(rstd[q], fmaf(tco[q], lns[h], raw[q]), lnc[h]);
-                            tp[h][j][q] = live ? v : 0.f;
+                    for (int h = 0; h < NH; ++h) {
+                        float hlp = 0.f, hrp = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { hlp += hlq[h][k]; hrp += hrq[h][k]; }
+                        const float rl = tv0 == 0 ? hlp : nbl[h], rr_ = tv0 + TV == T ? hrp : nbr[h];
+                        const bool okl = tv0 == 0 ? in_l : px0 + colL - 4 < W;
+                        const bool okr = tv0 + TV == T ? in_r : px0 + colR - 4 < W;
+                        const float outl = okl ? fmaf(srL, fmaf(smL, lns[h], rl), lnc[h]) : 0.f;
+                        const float outr = okr ? fmaf(srR, fmaf(smR, lns[h], rr_), lnc[h]) : 0.f;
+#pragma unroll
+                        for (int j = 0; j < TV; ++j) {
+                            const int jt = tv0 + j;
+                            const bool live = px0 + 16 * jt + 4 * kk < W;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float v = fmaf(rstd[j][q], fmaf(tco[j][q], lns[h], rawt[h][j][q]), lnc[h]);
+                                tp[h][j][q] = live ? v : 0.f;
+                            }
+                        }
+                        // horizontal neighbours across lane groups and tiles
+#pragma unroll
+                        for (int j = 0; j < TV; ++j) {
+                            const float same_l = __int_as_float(__builtin_amdgcn_ds_bpermute(nbr_prev, __float_as_int(tp[h][j][3])));
+                            const float oth_l = j > 0 ? __int_as_float(__builtin_amdgcn_ds_bpermute(nbr_prev, __float_as_int(tp[h][j > 0 ? j - 1 : 0][3]))) : outl;
+                            el[h][j] = kk == 0 ? oth_l : same_l;
+                            const float same_r = __int_as_float(__builtin_amdgcn_ds_bpermute(nbr_next, __float_as_int(tp[h][j][0])));
+                            const float oth_r = j + 1 < TV ? __int_as_float(__builtin_amdgcn_ds_bpermute(nbr_next, __float_as_int(tp[h][j + 1 < TV ? j + 1 : j][0]))) : outr;
+                            er[h][j] = kk == 3 ? oth_r : same_r;
                         }
                     }
-                    // horizontal neighbours across lane groups and tiles
+                } else {
+                // (the forms at their register limit -- gated: 128, exact fp32: 168 -- keep the reads next to their use)
+                    // ---- raw row out of the hand-off buffer; LayerNorm constants, bias, zero padding ----
+                    const float* sm = statm + (prow & 1) * ROWF;
+                    const float* sr = statr + (prow & 1) * ROWF;
 #pragma unroll
-                    for (int j = 0; j < TV; ++j) {
-                        const float same_l = __int_as_float(__builtin_amdgcn_ds_bpermute(nbr_prev, __float_as_int(tp[h][j][3])));
-                        const float oth_l = j > 0 ? __int_as_float(__builtin_amdgcn_ds_bpermute(nbr_prev, __float_as_int(tp[h][j > 0 ? j - 1 : 0][3]))) : outl;
-                        el[h][j] = kk == 0 ? oth_l : same_l;
-                        const float same_r = __int_as_float(__builtin_amdgcn_ds_bpermute(nbr_next, __float_as_int(tp[h][j][0])));
-                        const float oth_r = j + 1 < TV ? __int_as_float(__builtin_amdgcn_ds_bpermute(nbr_next, __float_as_int(tp[h][j + 1 < TV ? j + 1 : j][0]))) : outr;
-                        er[h][j] = kk == 3 ? oth_r : same_r;
+                    for (int h = 0; h < NH; ++h) {
+                        const int hs = GATE ? h * PAIRS + pair : slab;              // hand-off slot of this half
+                        const f32x4* hd = reinterpret_cast<const f32x4*>(hand) + hs * T * 64;
+                        const float* hh = halo + hs * 2 * 64 + lm;                  // + 16 * k: the k share
+                        // the pixel left of the first tile and right of the last one: a halo column of the strip, or
+                        // (GATE) a pixel of the other half of the strip, raw in the hand-off buffer
+                        float outl, outr;
+                        if (tv0 == 0) {
+                            float hlp = 0.f;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) hlp += hh[16 * k];
+                            outl = in_l ? fmaf(sr[3], fmaf(sm[3], lns[h], hlp), lnc[h]) : 0.f;
+                        } else {
+                            const int colx = 4 + 16 * tv0 - 1;
+                            const float raw = reinterpret_cast<const float*>(hd + (tv0 - 1) * 64 + 48 + lm)[3];
+                            outl = px0 + colx - 4 < W ? fmaf(sr[colx], fmaf(sm[colx], lns[h], raw), lnc[h]) : 0.f;
+                        }
+                        if (tv0 + TV == T) {
+                            float hrp = 0.f;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) hrp += hh[64 + 16 * k];
+                            outr = in_r ? fmaf(sr[4 + WT], fmaf(sm[4 + WT], lns[h], hrp), lnc[h]) : 0.f;
+                        } else {
+                            const int colx = 4 + 16 * (tv0 + TV);
+                            const float raw = reinterpret_cast<const float*>(hd + (tv0 + TV) * 64 + lm)[0];
+                            outr = px0 + colx - 4 < W ? fmaf(sr[colx], fmaf(sm[colx], lns[h], raw), lnc[h]) : 0.f;
+                        }
+#pragma unroll
+                        for (int j = 0; j < TV; ++j) {
+                            const int jt = tv0 + j;
+                            const f32x4 raw = hd[jt * 64 + lane];
+                            const f32x4 tco = *reinterpret_cast<const f32x4*>(&sm[4 + 16 * jt + 4 * kk]);
+                            const f32x4 rstd = *reinterpret_cast<const f32x4*>(&sr[4 + 16 * jt + 4 * kk]);
+                            const bool live = px0 + 16 * jt + 4 * kk < W;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const float v = fmaf(rstd[q], fmaf(tco[q], lns[h], raw[q]), lnc[h]);
+                                tp[h][j][q] = live ? v : 0.f;
+                            }
+                        }
+                        // horizontal neighbours across lane groups and tiles
+#pragma unroll
+                        for (int j = 0; j < TV; ++j) {
+                            const float same_l = __int_as_float(__builtin_amdgcn_ds_bpermute(nbr_prev, __float_as_int(tp[h][j][3])));
+                            const float oth_l = j > 0 ? __int_as_float(__builtin_amdgcn_ds_bpermute(nbr_prev, __float_as_int(tp[h][j > 0 ? j - 1 : 0][3]))) : outl;
+                            el[h][j] = kk == 0 ? oth_l : same_l;
+                            const float same_r = __int_as_float(__builtin_amdgcn_ds_bpermute(nbr_next, __float_as_int(tp[h][j][0])));
+                            const float oth_r = j + 1 < TV ? __int_as_float(__builtin_amdgcn_ds_bpermute(nbr_next, __float_as_int(tp[h][j + 1 < TV ? j + 1 : j][0]))) : outr;
+                            er[h][j] = kk == 3 ? oth_r : same_r;
+                        }
                     }
                 }
 #pragma unroll
                 for (int jj = 0; jj < TV0; ++jj) dw_tile(jj, prow);
             }
-            if (c == NC - 1 && have_prev) {
+            if (WS_ABL != 1 && WS_ABL != 2 && c == NC - 1 && have_prev) {
 #pragma unroll
                 for (int jj = TV0; jj < TV; ++jj) dw_tile(jj, prow);
             }

@@ -339,9 +339,10 @@ class Restormer(nn.Module):
             raise RuntimeError(f"Restormer expects a 4-D NCHW tensor, got shape {tuple(inp_img.shape)}")
         if inp_img.shape[-2] % 8 or inp_img.shape[-1] % 8:
             raise RuntimeError(f"Restormer needs H and W divisible by 8, got {tuple(inp_img.shape[-2:])}")
-        if self._two_streams_wanted(inp_img):
-            return self._forward_two_streams(inp_img)
-        return self._forward_one(inp_img)
+        out = self._forward_two_streams(inp_img) if self._two_streams_wanted(inp_img) else self._forward_one(inp_img)
+        if not torch.is_grad_enabled():
+            ops.trim_workspaces()          # a frame-sized scratch goes back to the allocator, crop-sized ones stay
+        return out
 
     # Inference of a batch on the bf16 path as two half-batches on two HIP streams.  The kernels of a block alternate
     # between ones that wait for issue slots / the matrix pipe (the fused 1x1 + depthwise kernels) and ones that wait

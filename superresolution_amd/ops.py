@@ -60,6 +60,17 @@ def release_workspaces() -> None:
     _workspaces.clear()
 
 
+def trim_workspaces(keep_bytes: Optional[int] = None) -> None:
+    """Hands scratch buffers above `keep_bytes` (default 4 GiB, ``RST_WORKSPACE_KEEP_GB``) back to torch's allocator:
+    a 4K frame needs a multi-GiB scratch that a process serving small crops afterwards should not keep.  Safe between
+    calls: a buffer is only ever used on the stream it is keyed on, which is also the stream it was allocated on."""
+    if keep_bytes is None:
+        import os
+        keep_bytes = int(float(os.environ.get("RST_WORKSPACE_KEEP_GB", "4")) * (1 << 30))
+    for key in [k for k, b in _workspaces.items() if b.numel() > keep_bytes]:
+        del _workspaces[key]
+
+
 def make_desc(B, C, H, W, heads, hidden, ln_with_bias, conv_bias) -> BlockDesc:
     return BlockDesc(int(B), int(C), int(H), int(W), int(heads), int(hidden), int(bool(ln_with_bias)), int(bool(conv_bias)))
 

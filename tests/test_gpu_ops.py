@@ -165,3 +165,20 @@ def test_conv3x3_fewout(shape, bias, residual):
     assert maxrel(got, ref) < TOL
     assert maxrel(xg.grad, xo.grad) < 1e-4
     assert maxrel(wg.grad, wo.grad) < 1e-4
+
+
+def test_scratch_above_the_keep_limit_is_handed_back():
+    """ops.workspace grows on demand; trim_workspaces (called by Restormer.forward after an inference call) drops the
+    buffers above the limit and keeps the small ones."""
+    from superresolution_amd import ops
+    dev = torch.device("cuda", torch.cuda.current_device())
+    ops.release_workspaces()
+    small = ops.workspace(2 << 20, dev)
+    assert ops.workspace(1 << 20, dev) is small                     # grow-only: a smaller request reuses it
+    ops.trim_workspaces(8 << 20)
+    assert ops.workspace(1 << 20, dev) is small
+    big = ops.workspace(64 << 20, dev)
+    assert big.numel() >= 64 << 20
+    ops.trim_workspaces(8 << 20)
+    assert not ops._workspaces
+    assert ops.workspace(1 << 20, dev).numel() < 64 << 20
