@@ -479,8 +479,13 @@ def main():
         # training step, gradient all-reduce) and config 4 (one 2048 x 2048 image in tiles dealt to the ranks, cores
         # gathered on rank 0).  Under torch.distributed.run they go through RCCL as they are (also with one rank), so a
         # 1/2/4/8-GPU sweep of the default command records them; in a plain one-process run they run without.  Never `value`.
-        out["train_bf16"] = side_train_bf16(dev, rank, world)
-        out["tiled_2048"] = side_tiled_2048(net, dev, rank, world)
+        # (a failure here -- the same on every rank, e.g. out of memory -- is recorded, not fatal to the line)
+        for key, fn in (("train_bf16", lambda: side_train_bf16(dev, rank, world)),
+                        ("tiled_2048", lambda: side_tiled_2048(net, dev, rank, world))):
+            try:
+                out[key] = fn()
+            except Exception as e:      # noqa: BLE001
+                out[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if rank == 0:
             # kernels of the training path that the inference workload does not launch, at a headline shape:
             # channel LayerNorm forward and backward (model/Restromer.py:26-52) at 16 x 96 x 256 x 256

@@ -25,5 +25,10 @@ for dt in fp32 bf16; do
   timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_$dt -- python3 $root/bench.py $extra $pm > $out/pmc_fetch_$dt.log 2>&1
   timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_$dt -- python3 $root/bench.py $extra $pm > $out/pmc_write_$dt.log 2>&1
 done
+for dt in fp32 bf16; do
+  extra=""; [ $dt = bf16 ] && extra="--dtype bf16"
+  timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_train_$dt -- python3 $root/bench.py --mode train $extra $pm > $out/pmc_fetch_train_$dt.log 2>&1
+  timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_train_$dt -- python3 $root/bench.py --mode train $extra $pm > $out/pmc_write_train_$dt.log 2>&1
+done
 timeout -s KILL 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_WAVES GRBM_GUI_ACTIVE --output-format csv -d $out/pmc_mfma -- python3 $root/bench.py $pm > $out/pmc_mfma.log 2>&1
 echo done > $out/DONE

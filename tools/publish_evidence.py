@@ -45,6 +45,12 @@ for dt, dst, dtype, what in (("fp32", "hbm_traffic", "f32", "bench.py default (R
     if f and w:
         subprocess.run([sys.executable, os.path.join(ROOT, "tools", "summarize_pmc.py"), "traffic", f, w,
                         os.path.join(prof, f"{prefix}_{dst}.json"), "3", what, dtype], check=True)
+for dt, dst, dtype, what in (("fp32", "train_hbm_traffic", "f32", "bench.py --mode train (Restormer dim=48 fp32 training step, 8x3x128x128)"),
+                             ("bf16", "train_bf16_hbm_traffic", "bf16", "bench.py --mode train --dtype bf16 (Restormer dim=48 bf16 training step, 8x3x128x128)")):
+    f, w = one(f"pmc_fetch_train_{dt}/*/*_counter_collection.csv"), one(f"pmc_write_train_{dt}/*/*_counter_collection.csv")
+    if f and w:
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "summarize_pmc.py"), "traffic", f, w,
+                        os.path.join(prof, f"{prefix}_{dst}.json"), "3", what, dtype, "8", "128", "train"], check=True)
 m = one("pmc_mfma/*/*_counter_collection.csv")
 if m:
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "summarize_pmc.py"), "mfma", m,

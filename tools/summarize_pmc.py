@@ -2,7 +2,7 @@
 """Turn rocprofv3 --pmc counter_collection.csv files of one bench.py run into the per-kernel-group
 JSON files kept under profiles/.
 
-usage: summarize_pmc.py traffic <fetch.csv> <write.csv> <out.json> <passes> [workload description] [dtype]
+usage: summarize_pmc.py traffic <fetch.csv> <write.csv> <out.json> <passes> [workload description] [dtype] [batch size mode]
        summarize_pmc.py mfma <counters.csv> <out.json>
 `passes` = workload passes in the profiled command (warm-up + timed + bench.py's own profiling pass).
 Kernel groups are the names bench.py's in-library profiler uses."""
@@ -29,7 +29,8 @@ def group(name):
         k = n.split("(")[0].replace("rst::", "")
         return {"attn_fold_kernel": "attn_fold", "attn_softmax_kernel": "attn_softmax", "ln_fold_weights_kernel": "ln_fold",
                 "reduce_slabs_vec_kernel": "reduce_slabs", "reduce_slabs_kernel": "reduce_slabs",
-                "gemm_f16s_prep_kernel": "gemm_f16s_prep", "conv3x3_f16s_prep_kernel": "conv3x3_f16s_prep"}.get(k, k)
+                "gemm_f16s_prep_kernel": "gemm_f16s_prep", "conv3x3_f16s_prep_kernel": "conv3x3_f16s_prep",
+                "dw_wgrad_pk_kernel": "pk_dw_wgrad", "gate_bwd_pk_kernel": "pk_gate_bwd", "gate_fwd_pk_kernel": "pk_gate"}.get(k, k)
     k, args = m.group(1), [a.strip() for a in m.group(2).split(",")]
     if k in ("gemm_nn_res_kernel", "gemm_nn_dma_kernel"):
         return "gemm_nn_ln" if args[3] == "true" else "gemm_nn"
@@ -53,6 +54,12 @@ def group(name):
         return "pk_gram"
     if k in ("pk_pack_kernel", "pk_unpack_kernel"):
         return k.replace("_kernel", "")
+    if k == "ln_bwd_pk_kernel":
+        return "pk_ln_bwd"
+    if k == "ln_fwd_pk_kernel":
+        return "pk_ln"
+    if k == "pwdw_ring_kernel":
+        return "pk_pwdw_gate" if args[1] == "true" else "pk_pwdw"
     if k == "pwdw_kernel":
         return "pwdw_gate" if args[2] == "true" else "pwdw"
     if k == "pwdw_ws_kernel":
@@ -81,7 +88,8 @@ def passes_of(name):
     return sum(1 for n in name.values() if "gram_pk_kernel" in n) / (LN_FOLD_PER_PASS / 2)
 
 
-def traffic(fetch_csv, write_csv, out, passes, workload="bench.py default (Restormer dim=48 fp32 inference, 16x3x256x256)", dtype="f32"):
+def traffic(fetch_csv, write_csv, out, passes, workload="bench.py default (Restormer dim=48 fp32 inference, 16x3x256x256)", dtype="f32",
+            batch=16, size=256, mode="infer"):
     import bench
     f, fn = load(fetch_csv)
     w, wn = load(write_csv)
@@ -103,7 +111,7 @@ def traffic(fetch_csv, write_csv, out, passes, workload="bench.py default (Resto
                "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of bench.py --steps 1 --warmup 1 --no-side-runs; "
                          "FETCH_SIZE doubled (gfx950 tallies 128-B read requests at 64 B); KB -> bytes x1024; "
                          f"{passes:g} passes in the profiled command",
-               "config": {"batch": 16, "size": 256, "mode": "infer"},
+               "config": {"batch": int(batch), "size": int(size), "mode": mode},
                "kernel_sources_sha": bench.kernel_sources_hash(),
                "total_bytes_per_step": round(sum(k["fetch_bytes_per_step"] + k["write_bytes_per_step"] for k in kernels.values())),
                "kernels": kernels}, open(out, "w"), indent=1)
@@ -135,6 +143,6 @@ def mfma(counters_csv, out):
 
 if __name__ == "__main__":
     if sys.argv[1] == "traffic":
-        traffic(*sys.argv[2:8])
+        traffic(*sys.argv[2:11])
     else:
         mfma(sys.argv[2], sys.argv[3])
