@@ -453,8 +453,9 @@ class Restormer(nn.Module):
     def _forward_bf16_train(self, inp_img):
         """Differentiable forward with bf16 activations (BASELINE config 3: bf16 storage, fp32 sums, fp32 master
         parameters and gradients), on the library's packed tensors from the first layer to the last: every stage of
-        TransformerBlocks is one autograd node that runs the packed bf16 kernels forward, keeps only each block's bf16
-        input and evaluates the block again for its backward (`bf16.stage`); the dense 3x3 convolutions with their
+        TransformerBlocks is one autograd node that runs the packed bf16 kernels forward and, per block, either saves
+        the intermediates its backward reads (while they fit) or keeps only the bf16 input and evaluates the block
+        again (`bf16.stage`); the dense 3x3 convolutions with their
         pixel (un)shuffles, the skip concatenations and the 1x1 reductions between the stages are the library's
         kernels in both directions (`bf16.conv3x3_train`, `cat_train`, `conv1x1_train`); the last layer adds the
         bilinear x2 of the input inside its kernel and returns fp32.  Returns the input's dtype."""
