@@ -133,12 +133,23 @@ pwdw_ws_kernel(PwDw a, int nstrips, int nsplit, int G, int ncols) {
     const int H = a.H, W = a.W;
     const int64_t HW = (int64_t)H * W;
 
-    // blocks 8 apart share an XCD (and its L2): the G channel groups of one strip are placed there
+    // blocks 8 apart share an XCD (and its L2): the G channel groups of one strip are placed there.  Plain form: every
+    // XCD also takes a contiguous range of columns with the strips of one row range next to each other, so the 16
+    // halo pixels a strip shares with its neighbour come out of the same L2 (6.97 -> 6.79 ms per step; the gated form
+    // loses with it, 5.53 -> 5.59, and keeps the interleaved order)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int g = slot % G;
-    const int col = (slot / G) * 8 + xcd;
-    if (col >= ncols) return;
-    const int sp = col % nsplit, strip = (col / nsplit) % nstrips, b = col / (nsplit * nstrips);
+    int col, sp, strip, b;
+    if constexpr (!GATE) {
+        const int cpx = (ncols + 7) >> 3;
+        col = xcd * cpx + slot / G;
+        if (slot / G >= cpx || col >= ncols) return;
+        strip = col % nstrips; sp = (col / nstrips) % nsplit; b = col / (nsplit * nstrips);
+    } else {
+        col = (slot / G) * 8 + xcd;
+        if (col >= ncols) return;
+        sp = col % nsplit; strip = (col / nsplit) % nstrips; b = col / (nsplit * nstrips);
+    }
     const int px0 = strip * WT;
     const int R0 = (int)((int64_t)H * sp / nsplit), R1 = (int)((int64_t)H * (sp + 1) / nsplit);
     const int ra = R0 > 0 ? R0 - 1 : 0, rb = R1 < H ? R1 : H - 1;
