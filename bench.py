@@ -52,7 +52,6 @@ def matrix_peak_tflops(name: str) -> float:
         return PEAK_F16_MATRIX_TFLOPS
     return PEAK_FP32_MATRIX_TFLOPS
 
-MFMA_KERNELS = {"gemm_nn", "gemm_nn_ln", "gemm_nt_splitk", "pwdw", "pwdw_gate"}
 
 
 def kernel_sources_hash() -> str:
@@ -184,18 +183,21 @@ def roofline_from(prof, traffic_of=lambda name: None):
     name = max(prof, key=lambda k: prof[k]["ms"])
     k = prof[name]
     sec = k["ms"] * 1e-3
-    if name in MFMA_KERNELS:
-        achieved = k["flops"] / sec / 1e12
-        roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4)}
+    # the roof the kernel is nearer to: its algorithmic bytes against the HBM peak, or its algorithmic flops against the
+    # matrix peak of the instruction its class runs on (exact fp32, split f16, bf16)
+    tf, gbs = k["flops"] / sec / 1e12, k["bytes"] / sec / 1e9
+    mpeak = matrix_peak_tflops(name)
+    if tf / mpeak > gbs / PEAK_HBM_GBS:
+        achieved = tf
+        roof = {"bound": "mfma", "achieved": round(achieved, 2), "peak": mpeak, "unit": "TFLOP/s", "frac": round(achieved / mpeak, 4)}
     else:
-        achieved = k["bytes"] / sec / 1e9
+        achieved = gbs
         roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": round(achieved / PEAK_HBM_GBS, 4)}
     peaks = measured_peaks()
     if peaks:
         key = {"mfma": "mfma_f32_16x16x4_TFLOPs", "hbm": "copy_GBps"}[roof["bound"]]
-        if key in peaks:
+        if key in peaks and (roof["bound"] == "hbm" or mpeak == PEAK_FP32_MATRIX_TFLOPS):
             roof["measured_peak"] = peaks[key]
             roof["frac_of_measured_peak"] = round(achieved / peaks[key], 4)
             roof["measured_peak_source"] = peaks["file"]

@@ -3,10 +3,12 @@
 # training step.  Output under gpurun_out/$1/.  Every GPU step has its own time limit; the script stops at the first failure.
 set -e
 tag=${1:-ev}
+part=${2:-all}          # "bench" = bench lines + kernel traces, "pmc" = the counter passes, "all" = both
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
+if [ $part != pmc ]; then
 timeout -k 10 400 python3 $root/bench.py > $out/bench.json 2> $out/bench.err
 timeout -k 10 200 python3 $root/bench.py --dtype bf16 --no-cpu-baseline --no-side-runs > $out/bench_bf16.json 2> $out/bench_bf16.err
 timeout -k 10 200 python3 $root/bench.py --mode train --no-cpu-baseline --no-side-runs > $out/bench_train.json 2> $out/bench_train.err
@@ -19,6 +21,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/k
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_bf16 -- python3 $root/bench.py --dtype bf16 $common > $out/kt_bf16.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_train -- python3 $root/bench.py --mode train $common > $out/kt_train.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_train_bf16 -- python3 $root/bench.py --mode train --dtype bf16 $common > $out/kt_train_bf16.log 2>&1
+fi
+if [ $part = bench ]; then echo done > $out/DONE_bench; exit 0; fi
+export RST_TWO_STREAMS=0
 pm="--steps 1 --warmup 1 --no-cpu-baseline --no-side-runs"
 for dt in fp32 bf16; do
   extra=""; [ $dt = bf16 ] && extra="--dtype bf16"
