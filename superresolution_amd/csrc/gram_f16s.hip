@@ -39,9 +39,9 @@ gram_f16s_kernel(const GemmNT g, int nsub, int walk) {
     const int64_t quarter = ((s1 - s0 + 3) / 4 + 31) / 32 * 32;
     const int64_t p0 = s0 + wave * quarter < s1 ? s0 + wave * quarter : s1;
     const int64_t p1 = p0 + quarter < s1 ? p0 + quarter : s1;
-    // this lane's row of tile 0 of each operand, at pixel 8 gq of a step
-    const float* Aq = g.A + (int64_t)b1 * g.a_s1 + (int64_t)b2 * g.a_s2 + (int64_t)(sm * T * 16 + l16) * g.lda + 8 * gq;
-    const float* Bk = g.Bm + (int64_t)b1 * g.b_s1 + (int64_t)b2 * g.b_s2 + (int64_t)(sn * T * 16 + l16) * g.ldb + 8 * gq;
+    // this lane's row of tile 0 of each operand; of a step of 32 pixels lane group gq takes pixels 8 gq .. 8 gq + 7
+    const float* Aq = g.A + (int64_t)b1 * g.a_s1 + (int64_t)b2 * g.a_s2 + (int64_t)(sm * T * 16 + l16) * g.lda;
+    const float* Bk = g.Bm + (int64_t)b1 * g.b_s1 + (int64_t)b2 * g.b_s2 + (int64_t)(sn * T * 16 + l16) * g.ldb;
 
     f32x4 acc1[T][T], acc2[T][T];
     float sq[2][T];
@@ -52,21 +52,26 @@ gram_f16s_kernel(const GemmNT g, int nsub, int walk) {
         for (int j = 0; j < T; ++j) { acc1[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     }
 
+    // The loop is  convert(step k) | issue the loads of step k + 1 | multiply(step k), in THAT order: the loads fly while
+    // the matrix pipe works, and the (counted) wait for them sits at the next conversion.  Left alone the compiler moved
+    // the conversion up to the loads and waited for them at once -- load latency + conversion + products in series, at
+    // two waves per SIMD.  The loads have no branch: a lane group past the end of the wave's range reads its row at a
+    // clamped pixel (valid memory) and is zeroed when converted, which only the last, partial step does.  (A second
+    // register buffer -- the loads of two steps in flight -- spills at three tiles: 256 registers + 56.)
     f32x4 raw[2][T][2];
     auto gload = [&](int64_t px) __attribute__((always_inline)) {
-        const bool ok = px + 8 * gq < p1;                     // whole groups of 8 pixels: chunk and N are multiples of 8
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        int64_t pl = px + 8 * gq;
+        if (pl + 8 > g.N) pl = g.N - 8;                       // (N is a multiple of 8, at least 8)
 #pragma unroll
         for (int t = 0; t < T; ++t) {
-            const f32x4* a = reinterpret_cast<const f32x4*>(Aq + (int64_t)t * 16 * g.lda + px);
-            const f32x4* b = reinterpret_cast<const f32x4*>(Bk + (int64_t)t * 16 * g.ldb + px);
-            raw[0][t][0] = ok ? a[0] : z; raw[0][t][1] = ok ? a[1] : z;
-            raw[1][t][0] = ok ? b[0] : z; raw[1][t][1] = ok ? b[1] : z;
+            const f32x4* a = reinterpret_cast<const f32x4*>(Aq + (int64_t)t * 16 * g.lda + pl);
+            const f32x4* b = reinterpret_cast<const f32x4*>(Bk + (int64_t)t * 16 * g.ldb + pl);
+            raw[0][t][0] = a[0]; raw[0][t][1] = a[1];
+            raw[1][t][0] = b[0]; raw[1][t][1] = b[1];
         }
     };
-    gload(p0);
-    for (int64_t px = p0; px < p1; px += 32) {
-        gr_h8 hi[2][T], lo[2][T];
+    gr_h8 hi[2][T], lo[2][T];
+    auto convert = [&](bool ok) __attribute__((always_inline)) {
 #pragma unroll
         for (int o = 0; o < 2; ++o)
 #pragma unroll
@@ -76,7 +81,7 @@ gram_f16s_kernel(const GemmNT g, int nsub, int walk) {
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        const gr_f32x2 vv = {raw[o][t][h][2 * e], raw[o][t][h][2 * e + 1]};
+                        const gr_f32x2 vv = {ok ? raw[o][t][h][2 * e] : 0.f, ok ? raw[o][t][h][2 * e + 1] : 0.f};
                         s = fmaf(vv[0], vv[0], fmaf(vv[1], vv[1], s));
                         const gr_h2 hh = __builtin_convertvector(vv, gr_h2);
                         const gr_f32x2 sc = vv * 2048.f;
@@ -87,7 +92,8 @@ gram_f16s_kernel(const GemmNT g, int nsub, int walk) {
                     }
                 sq[o][t] = s;
             }
-        gload(px + 32);                                       // (past the end: masked to zeros, never used)
+    };
+    auto multiply = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < T; ++i)
 #pragma unroll
@@ -96,6 +102,19 @@ gram_f16s_kernel(const GemmNT g, int nsub, int walk) {
                 acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(hi[0][i], lo[1][j], acc2[i][j], 0, 0, 0);
                 acc2[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lo[0][i], hi[1][j], acc2[i][j], 0, 0, 0);
             }
+    };
+    gload(p0);
+    int64_t px = p0;
+    for (; px + 32 <= p1; px += 32) {
+        convert(true);
+        __builtin_amdgcn_sched_barrier(0);
+        gload(px + 32);                                       // (past the end: clamped, masked or never used)
+        __builtin_amdgcn_sched_barrier(0);
+        multiply();
+    }
+    if (px < p1) {
+        convert(px + 8 * gq < p1);                            // whole groups of 8 pixels: chunk and N are multiples of 8
+        multiply();
     }
     // per-lane results of this wave, then the sum over the four waves
     float v[T * T * 4 + 2 * T];

@@ -242,3 +242,44 @@ def test_stage_saves_or_recomputes(monkeypatch):
         assert _cos(res[name][1], res["saved"][1]) > 0.999
         for k in res["saved"][2]:
             assert _cos(res[name][2][k], res["saved"][2][k]) > 0.995, (name, k)
+
+
+def test_stage_mixes_saved_and_recomputed_blocks(monkeypatch):
+    """When only some blocks of a stage fit the memory budget, those save their intermediates and the rest keep their
+    attention and recompute: the gradients are those of the all-recomputing stage to bf16 accuracy, block by block in the
+    right order."""
+    from superresolution_amd import bf16
+    from superresolution_amd.model.Restromer import TransformerBlock
+    torch.manual_seed(11)
+    blocks = torch.nn.Sequential(*[TransformerBlock(48, 1, 1.25, False, "WithBias") for _ in range(3)]).cuda()
+    x = torch.randn(2, 48, 16, 16, device="cuda").bfloat16()
+    r = torch.randn(2, 48, 16, 16, device="cuda")
+
+    def run():
+        for p in blocks.parameters():
+            p.grad = None
+        xa = x.clone().requires_grad_(True)
+        (bf16.stage(xa, blocks).float() * r).sum().backward()
+        return xa.grad.float().clone(), {k: p.grad.clone() for k, p in blocks.named_parameters()}
+
+    monkeypatch.setenv("RST_BF16_SAVE", "0")
+    ref = run()
+    monkeypatch.delenv("RST_BF16_SAVE")
+    # a budget (a quarter of "free" memory) that holds the buffers of one block and a half
+    lib = bf16._lib.load()
+    need = bf16._saved_bytes(lib, bf16.pack(x), 1, blocks[0].ffn.hidden_features, blocks[0]._params())
+    modes = []
+    real_into = bf16._block_into
+
+    def spy(lib_, src, dst, heads, hidden, params, cache, keep_attn=False, save=False):
+        modes.append("saved" if save else ("kept" if keep_attn else "input"))
+        return real_into(lib_, src, dst, heads, hidden, params, cache, keep_attn=keep_attn, save=save)
+    monkeypatch.setattr(bf16, "_block_into", spy)
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda *a, **k: (int(need * 1.5) * 4, 1 << 40))
+    monkeypatch.setattr(torch.cuda, "memory_reserved", lambda *a, **k: 0)
+    monkeypatch.setattr(torch.cuda, "memory_allocated", lambda *a, **k: 0)
+    got = run()
+    assert modes == ["saved", "kept", "kept"], modes
+    assert _cos(got[0], ref[0]) > 0.999
+    for k in ref[1]:
+        assert _cos(got[1][k], ref[1][k]) > 0.995, k
