@@ -108,7 +108,7 @@ gram_f16s_kernel(const GemmNT g, int nsub, int walk) {
     for (; px + 32 <= p1; px += 32) {
         convert(true);
         __builtin_amdgcn_sched_barrier(0);
-        gload(px + 32);                                       // (past the end: clamped, masked or never used)
+        if (px + 32 < p1) gload(px + 32);                     // (wave-uniform; a partial step: clamped, masked when converted)
         __builtin_amdgcn_sched_barrier(0);
         multiply();
     }
