@@ -171,8 +171,9 @@ def conv3x3_fewout(p: Packed, weight: torch.Tensor, bias: Optional[torch.Tensor]
 
 class PreparedCache:
     """Prepared weights of one block (rst_bf16_block_prepare), rebuilt when a parameter tensor is replaced or
-    modified in place (torch bumps ``_version`` on every in-place write, including optimizer steps, ``copy_`` and
-    ``load_state_dict``).  A write through ``param.data`` does NOT move ``_version``: call :meth:`invalidate` (or
+    modified in place (torch bumps ``_version`` on every in-place write, including ``copy_`` and ``load_state_dict``)
+    and after every optimiser step of the process (``ops.weights_generation``: fused optimisers do not move
+    ``_version``).  A write through ``param.data`` is invisible to both: call :meth:`invalidate` (or
     ``Restormer.invalidate_prepared()``) after such a write."""
     __slots__ = ("key", "blob")
 
@@ -184,7 +185,8 @@ class PreparedCache:
 
     @staticmethod
     def _key(params, device):
-        return tuple((n, t.data_ptr(), t._version) for n, t in params.items() if t is not None) + (str(device),)
+        from .ops import weights_generation
+        return tuple((n, t.data_ptr(), t._version) for n, t in params.items() if t is not None) + (str(device), weights_generation())
 
     def is_current(self, params, device) -> bool:
         """True when the kept weights were prepared from exactly these parameter tensors (nothing would be launched)."""

@@ -550,6 +550,28 @@ def feed_forward(x, hidden, pin_weight, pin_bias, dw_weight, dw_bias, pout_weigh
                         pin_weight, pin_bias, dw_weight, dw_bias, pout_weight, pout_bias)
 
 
+# Every optimiser step of the process moves this counter (a global torch hook), and the prepared-weight caches carry
+# it in their keys: torch's fused optimisers update parameters without moving their version counters, so a version
+# alone would let an evaluation after `optimizer.step()` run on the weights of the previous preparation.
+_optimizer_steps = [0]
+
+
+def _count_optimizer_step(optimizer, args, kwargs):
+    _optimizer_steps[0] += 1
+
+
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook
+    _register_step_hook(_count_optimizer_step)
+except ImportError:          # a torch without global optimiser hooks: the version counters and the mode switches remain
+    pass
+
+
+def weights_generation() -> int:
+    """Number of optimiser steps this process has taken (part of every prepared-weight cache key)."""
+    return _optimizer_steps[0]
+
+
 class PreparedBlock:
     """The input-independent part of one block's fp32 inference (rst_block_prepare: LayerNorm-folded weights, operand
     fragments), kept between calls and rebuilt when a parameter tensor is replaced or modified in place (torch bumps
@@ -567,7 +589,7 @@ class PreparedBlock:
     def _key(tensors, device):
         # (the prepared form depends on which instructions the products run on: rst_set_exact_fp32)
         return (tuple((n, t.data_ptr(), t._version) for n, t in tensors.items() if t is not None) +
-                (str(device), int(_lib.load().rst_get_exact_fp32())))
+                (str(device), int(_lib.load().rst_get_exact_fp32()), _optimizer_steps[0]))
 
     def is_current(self, tensors, device) -> bool:
         """True when the kept buffer was prepared from exactly these parameter tensors (nothing would be launched)."""

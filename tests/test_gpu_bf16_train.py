@@ -177,3 +177,28 @@ def test_plain_fused_adam_loop_then_eval_sees_the_new_weights(autocast):
         want = net(x).float()
     assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
     assert float((got - before).abs().max()) > 1e-2 * float(want.abs().max())     # the steps did change the output
+
+
+@pytest.mark.parametrize("autocast", [False, True])
+def test_fused_adam_steps_without_a_mode_switch_are_seen(autocast):
+    """The same loop with NO train()/eval() call between the steps and the evaluation (a script that evaluates under
+    no_grad in whatever mode the module is in): every optimiser step of the process moves the generation that the
+    prepared-weight caches are keyed on, so the evaluation still runs on the updated weights."""
+    from superresolution_amd import ops
+    net, x, tgt = _net(recipe.MODEL_CASES[1])
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        before = net(x).float()
+    gen = ops.weights_generation()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
+    for _ in range(2):
+        opt.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+            (net(x).float() - tgt).abs().mean().backward()
+        opt.step()
+    assert ops.weights_generation() == gen + 2
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        got = net(x).float()
+        net.invalidate_prepared()
+        want = net(x).float()
+    assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    assert float((got - before).abs().max()) > 1e-2 * float(want.abs().max())
