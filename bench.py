@@ -544,8 +544,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline_train(net, args.dtype == "bf16")
         print(json.dumps(out), flush=True)
     barrier(world)
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
 
 
