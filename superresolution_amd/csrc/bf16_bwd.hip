@@ -585,29 +585,32 @@ lnlin_dw_kernel(const float* __restrict__ G, const float* __restrict__ S, const 
     dW[e] = v;
     if (dbias != nullptr && c == 0) dbias[m] = S[pos];
 }
-// dgamma[c] = sum_m W[m][c] G[pos(m)][c],  dbeta[c] = sum_m W[m][c] S[pos(m)]; 16 columns x 16 row phases per block
-__global__ void __launch_bounds__(256)
+// dgamma[c] = sum_m W[m][c] G[pos(m)][c],  dbeta[c] = sum_m W[m][c] S[pos(m)]; 16 columns x 64 row phases per block
+// (a block per 16 columns is all the parallelism there is across blocks -- 3 to 24 of them -- so the rows are spread
+// over 1024 threads: the kernel is a chain of dependent cache misses per thread, 7.7 us on average with 16 phases)
+constexpr int LNLIN_PH = 64;
+__global__ void __launch_bounds__(16 * LNLIN_PH)
 lnlin_dgamma_kernel(const float* __restrict__ G, const float* __restrict__ S, const float* __restrict__ W,
                     float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int C, int seg, int seg_pad) {
-    __shared__ float red[2][16][17];
+    __shared__ float red[2][LNLIN_PH][17];
     const int cl = threadIdx.x & 15, ph = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     float a = 0.f, bsum = 0.f;
     if (c < C) {
-        // four rows in flight per thread: the loop is a chain of dependent cache misses otherwise
+        // four rows in flight per thread
         float a4[4] = {0.f, 0.f, 0.f, 0.f}, b4[4] = {0.f, 0.f, 0.f, 0.f};
         int m = ph;
-        for (; m + 48 < M; m += 64) {
+        for (; m + 3 * LNLIN_PH < M; m += 4 * LNLIN_PH) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int mm = m + 16 * u;
+                const int mm = m + LNLIN_PH * u;
                 const int pos = dst_position(mm, seg, seg_pad);
                 const float w = W[(int64_t)mm * C + c];
                 a4[u] = fmaf(w, G[(int64_t)pos * C + c], a4[u]);
                 b4[u] = fmaf(w, S[pos], b4[u]);
             }
         }
-        for (; m < M; m += 16) {
+        for (; m < M; m += LNLIN_PH) {
             const int pos = dst_position(m, seg, seg_pad);
             const float w = W[(int64_t)m * C + c];
             a4[0] = fmaf(w, G[(int64_t)pos * C + c], a4[0]);
@@ -620,8 +623,8 @@ lnlin_dgamma_kernel(const float* __restrict__ G, const float* __restrict__ S, co
     __syncthreads();
     if (ph == 0 && c < C) {
         float ga = 0.f, gb = 0.f;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { ga += red[0][i][cl]; gb += red[1][i][cl]; }
+#pragma unroll 8
+        for (int i = 0; i < LNLIN_PH; ++i) { ga += red[0][i][cl]; gb += red[1][i][cl]; }
         dgamma[c] = ga;
         if (dbeta != nullptr) dbeta[c] = gb;
     }
@@ -631,7 +634,7 @@ int lnlin_grads_launch(const float* G, const float* S, const float* W, const flo
     RST_REQUIRE(G && S && W && gamma && dW && dgamma && M > 0 && C > 0, "bf16 LayerNorm + 1x1 gradients: bad operand");
     hipLaunchKernelGGL(lnlin_dw_kernel, dim3((unsigned)cdiv((int64_t)M * C, 256)), dim3(256), 0, stream, G, S, gamma, beta, dW, dbias, M, C, seg, seg_pad);
     RST_LAUNCH_CHECK();
-    hipLaunchKernelGGL(lnlin_dgamma_kernel, dim3((unsigned)cdiv(C, 16)), dim3(256), 0, stream, G, S, W, dgamma, dbeta, M, C, seg, seg_pad);
+    hipLaunchKernelGGL(lnlin_dgamma_kernel, dim3((unsigned)cdiv(C, 16)), dim3(16 * LNLIN_PH), 0, stream, G, S, W, dgamma, dbeta, M, C, seg, seg_pad);
     RST_LAUNCH_CHECK();
     return RST_OK;
 }
