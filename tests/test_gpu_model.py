@@ -159,3 +159,32 @@ def test_activations_beyond_the_f16_range_never_return_inf():
         finally:
             lib.rst_set_exact_fp32(0)
         assert bool(torch.isfinite(y).all())
+
+
+def test_input_contract_of_the_module():
+    """What the reference's callers may hand the network (model/Restromer.py:385-433): non-contiguous views are
+    accepted and give the result of their contiguous copy (to the run-to-run spread of the atomics); a shape the network cannot take (not 4-D, H or W not a
+    multiple of 8 -- the reference fails inside torch.cat there) is refused with a message, before any kernel runs;
+    an empty batch is refused too."""
+    from superresolution_amd.model.Restromer import Restormer
+    torch.manual_seed(3)
+    net = Restormer(inp_channels=3, out_channels=3, dim=48).cuda().eval()
+    big = torch.rand(2, 3, 40, 48, device="cuda")
+    view = big[:, :, 4:36, 8:40]                                   # 32 x 32 window, strides of the larger tensor
+    assert not view.is_contiguous()
+    # Two runs on the same values differ in the last bit (the Gram matrix is summed over pixel ranges with
+    # floating-point atomics, in the order the blocks arrive), so "the same result" means to 2e-6 here.
+    with torch.no_grad():
+        a = net(view)
+        b = net(view.contiguous())
+    torch.testing.assert_close(a, b, rtol=0, atol=2e-6)
+    window = big[:, :, :32, :32]
+    chan_last = window.contiguous(memory_format=torch.channels_last)
+    assert not chan_last.is_contiguous()
+    with torch.no_grad():
+        torch.testing.assert_close(net(chan_last), net(window.contiguous()), rtol=0, atol=2e-6)
+    for bad in (torch.rand(3, 32, 32, device="cuda"), torch.rand(1, 3, 30, 32, device="cuda"), torch.rand(1, 3, 32, 36, device="cuda")):
+        with pytest.raises(RuntimeError):
+            net(bad)
+    with pytest.raises(RuntimeError):
+        net(torch.rand(0, 3, 32, 32, device="cuda"))
