@@ -212,12 +212,17 @@ int rst_conv3x3_fewout_up2_fwd(const float* x, const float* weight, const float*
 /* :203-215.  x: [B, Cin, H, W]; weight: [Cout, Cin, 3, 3]; bias [Cout] or NULL. */
 /* y: mode 0 [B, Cout, H, W]; mode 1 [B, 4 Cout, H/2, W/2]; mode 2              */
 /* [B, Cout/4, 2H, 2W].  The product runs on the f16 matrix instructions with   */
-/* both operands split in two (fp32 accuracy; |x| < 65504).  Shapes: W a        */
-/* multiple of 8 (rows of 128-pixel tiles, the last one masked; 32 / 64-pixel   */
-/* images in tiles of 4 / 2 rows), mode 1: even H, mode 2: Cout % 4 == 0         */
-/* (rst_conv3x3_supported); the workspace holds the split weights.              */
+/* both operands split in two (fp32 accuracy; |x| < 65504).  Shapes: any W      */
+/* (rows of 128-pixel tiles, the last one masked; 32 / 64-pixel images in tiles */
+/* of 4 / 2 rows; a width that is not a multiple of 8 runs on a copy with zero   */
+/* columns added in the workspace), mode 1: even H and W, mode 2: Cout % 4 == 0  */
+/* (rst_conv3x3_supported).  The workspace holds the split weights             */
+/* (rst_conv3x3_workspace_bytes: enough whenever W % 8 == 0) and the padded      */
+/* copies (rst_conv3x3_fwd_workspace_bytes: enough for the shape given; 0 for    */
+/* an unsupported one).                                                          */
 /* ------------------------------------------------------------------------- */
 size_t rst_conv3x3_workspace_bytes(int32_t Cin, int32_t Cout);
+size_t rst_conv3x3_fwd_workspace_bytes(int32_t B, int32_t Cin, int32_t Cout, int32_t H, int32_t W, int32_t shuffle_mode);
 int32_t rst_conv3x3_supported(int32_t Cin, int32_t Cout, int32_t H, int32_t W, int32_t shuffle_mode);
 int rst_conv3x3_fwd(const float* x, const float* weight, const float* bias, float* y,
                     int32_t B, int32_t Cin, int32_t Cout, int32_t H, int32_t W, int32_t shuffle_mode,
@@ -226,8 +231,9 @@ int rst_conv3x3_fwd(const float* x, const float* weight, const float* bias, floa
 /* from the forward's input x [B][Cin][H][W] and the gradient dy of its (shuffled)   */
 /* output: dx (NULL: not wanted), dweight [Cout][Cin][3][3], dbias [Cout] (NULL:     */
 /* none), overwritten.  Exact-fp32 products (gradients are far below f16's range).   */
-/* Any Cin, Cout (also the last layer's 48 -> 3), W % 4 == 0; shuffle_mode as in the */
-/* forward.  The workspace query returns 0 for unsupported shapes.                   */
+/* Any Cin, Cout (also the last layer's 48 -> 3), any W (not a multiple of 4: on     */
+/* zero-padded copies in the workspace); shuffle_mode as in the forward.  The        */
+/* workspace query returns 0 for unsupported shapes.                                 */
 size_t rst_conv3x3_bwd_workspace_bytes(int32_t B, int32_t Cin, int32_t Cout, int32_t H, int32_t W,
                                        int32_t shuffle_mode, int32_t want_dx, int32_t want_bias);
 int rst_conv3x3_bwd(const float* x, const float* dy, const float* weight, float* dx, float* dweight, float* dbias,

@@ -62,6 +62,7 @@ SIGNATURES = {
     "rst_dwconv3x3_fwd": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, _P]),
     "rst_conv3x3_fewout_fwd": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),
     "rst_conv3x3_workspace_bytes": (c_size_t, [c_int32, c_int32]),
+    "rst_conv3x3_fwd_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
     "rst_conv3x3_supported": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32]),
     "rst_conv3x3_fwd": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, _P, c_size_t, _P]),
     "rst_conv3x3_fewout_up2_fwd": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_int32, _P]),

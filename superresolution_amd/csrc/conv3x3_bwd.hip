@@ -111,14 +111,36 @@ int im2col_launch(const float* src, float* dst, int B, int C, int H, int W, hipS
 }  // namespace
 
 bool conv3x3_bwd_supported(int Cin, int Cout, int H, int W, int mode) {
-    if (Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || mode < 0 || mode > 2 || W % 4 != 0) return false;
+    if (Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || mode < 0 || mode > 2) return false;
     if (mode == 1 && (H % 2 != 0 || W % 2 != 0)) return false;
     if (mode == 2 && Cout % 4 != 0) return false;
     return true;
 }
 
+// The kernels take widths that are multiples of 4.  Any other width runs on copies of x and dy with zero columns added
+// on the right: zero columns of dy add nothing to the weight and bias gradients, zero columns of x are the padding the
+// convolution has there anyway, and the columns of dx past the image are dropped.
+struct Conv3BwdPad { float *xp, *dyp, *dxp; void* inner; size_t inner_bytes; };
+
+static void conv3f_bwd_pad_carve(int B, int Cin, int Cout, int H, int W, int Wp, int mode, bool want_dx, bool want_bias, CarveF& cv,
+                                 Conv3BwdPad& p) {
+    p.xp = cv.floats((size_t)B * Cin * H * Wp);
+    p.dyp = cv.floats((size_t)B * Cout * H * Wp);                 // every mode's dy has Cout * H * W values per sample
+    p.dxp = want_dx ? cv.floats((size_t)B * Cin * H * Wp) : nullptr;
+    CarveF in(nullptr); Conv3BwdF b{};
+    conv3f_bwd_carve(B, Cin, Cout, H, Wp, mode, want_dx, want_bias, in, b);
+    p.inner_bytes = in.total();
+    p.inner = cv.bytes(p.inner_bytes);
+}
+
 size_t conv3x3_bwd_ws_bytes(int B, int Cin, int Cout, int H, int W, int mode, int want_dx, int want_bias) {
-    CarveF cv(nullptr); Conv3BwdF b{};
+    CarveF cv(nullptr);
+    if (W % 4 != 0) {
+        Conv3BwdPad p{};
+        conv3f_bwd_pad_carve(B, Cin, Cout, H, W, (int)round_up(W, 4), mode, want_dx != 0, want_bias != 0, cv, p);
+        return cv.total();
+    }
+    Conv3BwdF b{};
     conv3f_bwd_carve(B, Cin, Cout, H, W, mode, want_dx != 0, want_bias != 0, cv, b);
     return cv.total();
 }
@@ -127,13 +149,26 @@ int conv3x3_bwd_launch(const float* x, const float* dy, const float* w, float* d
                        int Cout, int H, int W, int mode, void* ws, size_t ws_bytes, hipStream_t stream) {
     RST_REQUIRE(x && dy && w && dweight && B > 0, "conv3x3 backward: bad operand");
     RST_REQUIRE(conv3x3_bwd_supported(Cin, Cout, H, W, mode),
-                "conv3x3 backward: unsupported shape Cin=%d Cout=%d H=%d W=%d mode=%d (W %% 4 == 0; unshuffle: even H; shuffle: Cout %% 4 == 0)",
+                "conv3x3 backward: unsupported shape Cin=%d Cout=%d H=%d W=%d mode=%d (unshuffle: even H and W; shuffle: Cout %% 4 == 0)",
                 Cin, Cout, H, W, mode);
     RST_REQUIRE(aligned16(x) && aligned16(dy) && (dx == nullptr || aligned16(dx)), "conv3x3 backward: tensors must be 16-byte aligned");
     const bool want_dx = dx != nullptr, want_bias = dbias != nullptr;
     const size_t need = conv3x3_bwd_ws_bytes(B, Cin, Cout, H, W, mode, want_dx, want_bias);
     if (ws == nullptr || !aligned16(ws) || ws_bytes < need)
         return fail(RST_ERR_WORKSPACE, "conv3x3 backward: workspace %zu < %zu bytes", ws_bytes, need);
+    if (W % 4 != 0) {
+        const int Wp = (int)round_up(W, 4);
+        CarveF pc(ws); Conv3BwdPad p{};
+        conv3f_bwd_pad_carve(B, Cin, Cout, H, W, Wp, mode, want_dx, want_bias, pc, p);
+        RST_TRY(copy_cols_launch(x, p.xp, (int64_t)B * Cin * H, W, Wp, stream));
+        // rows of dy: mode 0 [Cout][H] x W, mode 1 [4 Cout][H / 2] x W / 2, mode 2 [Cout / 4][2 H] x 2 W
+        const int64_t rows = (int64_t)B * Cout * H * (mode == 1 ? 2 : 1) / (mode == 2 ? 2 : 1);
+        const int f2 = mode == 1 ? 1 : mode == 2 ? 4 : 2;             // twice the width factor
+        RST_TRY(copy_cols_launch(dy, p.dyp, rows, W * f2 / 2, Wp * f2 / 2, stream));
+        RST_TRY(conv3x3_bwd_launch(p.xp, p.dyp, w, p.dxp, dweight, dbias, B, Cin, Cout, H, Wp, mode, p.inner, p.inner_bytes, stream));
+        if (want_dx) RST_TRY(copy_cols_launch(p.dxp, dx, (int64_t)B * Cin * H, Wp, W, stream));
+        return RST_OK;
+    }
     CarveF cv(ws); Conv3BwdF b{};
     conv3f_bwd_carve(B, Cin, Cout, H, W, mode, want_dx, want_bias, cv, b);
     const int64_t N = (int64_t)H * W;

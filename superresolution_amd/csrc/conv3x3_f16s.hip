@@ -366,6 +366,16 @@ conv3x3_fewin_kernel(const float* __restrict__ x, const float* __restrict__ w, c
     }
 }
 
+// dst[r][c] = c < ws ? src[r][c] : 0 for rows of ws -> wd values: zero padding of the columns (wd > ws) or a crop (wd < ws)
+__global__ void __launch_bounds__(256)
+copy_cols_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n, int ws, int wd) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t r = i / wd;
+    const int c = (int)(i - r * wd);
+    dst[i] = c < ws ? src[r * ws + c] : 0.f;
+}
+
 int c3_pick_rt(int M) {
     static const int forced = getenv("RST_CONV_RT") != nullptr ? atoi(getenv("RST_CONV_RT")) : 0;      // A/B runs
     if (forced >= 1 && forced <= 3) return forced;      // (measured: the highest block that pads least is the fastest here)
@@ -387,10 +397,22 @@ static int c3_tile_width(int H, int W) {
     if ((W == 32 && H % 4 == 0) || (W == 64 && H % 2 == 0)) return W;
     return 128;
 }
+int copy_cols_launch(const float* src, float* dst, int64_t rows, int ws, int wd, hipStream_t stream) {
+    const int64_t n = rows * wd;
+    RST_REQUIRE(src && dst && rows > 0 && ws > 0 && wd > 0 && cdiv(n, 256) < (1ll << 31), "copy_cols: bad shape");
+    ProfScope prof(stream, "copy_cols", 0.0, 4.0 * rows * ((ws < wd ? ws : wd) + wd));
+    hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, stream, src, dst, n, ws, wd);
+    RST_LAUNCH_CHECK();
+    return RST_OK;
+}
+
+// the kernels take widths that are multiples of 8; any other width runs on a copy with zero columns added on the right
+// (the zero padding of the convolution itself, so the result is the same) whose result is cropped
+static bool c3_kernel_width(int W) { return W % 8 == 0; }
+
 bool conv3x3_f16s_supported(int Cin, int Cout, int H, int W, int mode) {
     if (Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return false;
-    if (W % 8 != 0) return false;
-    if (mode == 1 && (H % 2 != 0)) return false;
+    if (mode == 1 && (H % 2 != 0 || W % 2 != 0)) return false;
     if (mode == 2 && Cout % 4 != 0) return false;
     return mode >= 0 && mode <= 2;
 }
@@ -399,12 +421,38 @@ size_t conv3x3_f16s_ws_bytes(int Cin, int Cout) {
     return (size_t)round_up(Cout, 16) * 9 * (size_t)round_up(Cin, 32) * 4;
 }
 
+// workspace of a call: the split weights, and for a width that is not a multiple of 8 the padded input and result
+size_t conv3x3_f16s_fwd_ws_bytes(int B, int Cin, int Cout, int H, int W) {
+    size_t n = round_up(conv3x3_f16s_ws_bytes(Cin, Cout), (size_t)256);
+    if (!c3_kernel_width(W)) {
+        const size_t Wp = (size_t)round_up(W, 8);
+        n += round_up((size_t)B * Cin * H * Wp * 4, (size_t)256) + round_up((size_t)B * Cout * H * Wp * 4, (size_t)256);
+    }
+    return n;
+}
+
 int conv3x3_f16s_launch(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int H, int W,
                         int mode, void* ws, size_t ws_bytes, hipStream_t stream) {
     RST_REQUIRE(x && w && y && B > 0 && B <= 65535, "conv3x3: bad operand");
     RST_REQUIRE(conv3x3_f16s_supported(Cin, Cout, H, W, mode),
-                "conv3x3: unsupported shape Cin=%d Cout=%d H=%d W=%d mode=%d (W a multiple of 8; unshuffle: even H; shuffle: Cout %% 4 == 0)", Cin, Cout, H, W, mode);
+                "conv3x3: unsupported shape Cin=%d Cout=%d H=%d W=%d mode=%d (unshuffle: even H and W; shuffle: Cout %% 4 == 0)", Cin, Cout, H, W, mode);
     RST_REQUIRE(aligned16(x) && aligned16(y), "conv3x3: tensors must be 16-byte aligned");
+    if (!c3_kernel_width(W)) {
+        const size_t need = conv3x3_f16s_fwd_ws_bytes(B, Cin, Cout, H, W);
+        if (ws == nullptr || ws_bytes < need || !aligned16(ws))
+            return fail(RST_ERR_WORKSPACE, "conv3x3: workspace %zu < %zu bytes (rst_conv3x3_fwd_workspace_bytes)", ws_bytes, need);
+        const int Wp = round_up(W, 8);
+        const size_t wb = round_up(conv3x3_f16s_ws_bytes(Cin, Cout), (size_t)256);
+        const size_t xb = round_up((size_t)B * Cin * H * Wp * 4, (size_t)256);
+        float* xp = reinterpret_cast<float*>(static_cast<char*>(ws) + wb);
+        float* yp = reinterpret_cast<float*>(static_cast<char*>(ws) + wb + xb);
+        RST_TRY(copy_cols_launch(x, xp, (int64_t)B * Cin * H, W, Wp, stream));
+        RST_TRY(conv3x3_f16s_launch(xp, w, bias, yp, B, Cin, Cout, H, Wp, mode, ws, wb, stream));
+        // rows of the result: mode 0 [Cout][H] x W, mode 1 [4 Cout][H / 2] x W / 2, mode 2 [Cout / 4][2 H] x 2 W
+        const int64_t rows = (int64_t)B * Cout * H * (mode == 1 ? 2 : 1) / (mode == 2 ? 2 : 1);
+        const int f2 = mode == 1 ? 1 : mode == 2 ? 4 : 2;             // twice the width factor
+        return copy_cols_launch(yp, y, rows, Wp * f2 / 2, W * f2 / 2, stream);
+    }
     if (ws == nullptr || ws_bytes < conv3x3_f16s_ws_bytes(Cin, Cout) || !aligned16(ws))
         return fail(RST_ERR_WORKSPACE, "conv3x3: workspace %zu < %zu bytes", ws_bytes, conv3x3_f16s_ws_bytes(Cin, Cout));
     static const bool fewin_off = getenv("RST_CONV_FEWIN") != nullptr && getenv("RST_CONV_FEWIN")[0] == '0';   // A/B runs
@@ -458,6 +506,10 @@ int conv3x3_f16s_launch(const float* x, const float* w, const float* bias, float
 extern "C" {
 size_t rst_conv3x3_workspace_bytes(int32_t Cin, int32_t Cout) {
     return (Cin > 0 && Cout > 0) ? rst::conv3x3_f16s_ws_bytes(Cin, Cout) : 0;
+}
+size_t rst_conv3x3_fwd_workspace_bytes(int32_t B, int32_t Cin, int32_t Cout, int32_t H, int32_t W, int32_t shuffle_mode) {
+    if (B <= 0 || !rst::conv3x3_f16s_supported(Cin, Cout, H, W, shuffle_mode)) return 0;
+    return rst::conv3x3_f16s_fwd_ws_bytes(B, Cin, Cout, H, W);
 }
 int32_t rst_conv3x3_supported(int32_t Cin, int32_t Cout, int32_t H, int32_t W, int32_t shuffle_mode) {
     // (with the exact-fp32 switch on there is no kernel for it here: callers fall back to their own convolution)

@@ -150,6 +150,8 @@ int conv3x3_fewout_launch(const Conv3Args& a, hipStream_t stream);
 
 // ---- shuffle.hip ----
 int pixel_shuffle2_launch(bool shuffle, const float* src, float* dst, int B, int C, int H, int W, hipStream_t stream);
+// conv3x3_f16s.hip: dst[r][c] = c < ws ? src[r][c] : 0 over rows of ws -> wd values (zero columns added, or a crop)
+int copy_cols_launch(const float* src, float* dst, int64_t rows, int ws, int wd, hipStream_t stream);
 
 // ---- attn_small.hip ----
 int attn_softmax_launch(const float* gram_partial, const float* sqq_partial, const float* sqk_partial,

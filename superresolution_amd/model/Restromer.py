@@ -172,7 +172,7 @@ class OverlapPatchEmbed(nn.Module):
     def forward(self, x):
         if ops.conv3x3_supported(x, self.proj.weight, 0):
             return ops.conv3x3(x, self.proj.weight, self.proj.bias, 0)
-        return self.proj(x)            # a width that is not a multiple of 8 (e.g. the 1/8 level of a 264-pixel image): torch
+        return self.proj(x)            # not an fp32 ROCm tensor, or the exact-fp32 switch is on: torch's convolution
 
 
 class _Permute(nn.Module):
@@ -200,7 +200,7 @@ class Downsample(nn.Module):
         conv = self.body[0]
         if ops.conv3x3_supported(x, conv.weight, 1):
             return ops.conv3x3(x, conv.weight, conv.bias, 1)        # convolution and PixelUnshuffle(2) in one kernel
-        return self.body(x)                # a width that is not a multiple of 8: torch's convolution, the library's shuffle
+        return self.body(x)                # not an fp32 ROCm tensor, or the exact-fp32 switch is on: torch's convolution
 
 
 class Upsample(nn.Module):
@@ -216,7 +216,7 @@ class Upsample(nn.Module):
         conv = self.body[0]
         if ops.conv3x3_supported(x, conv.weight, 2):
             return ops.conv3x3(x, conv.weight, conv.bias, 2)        # convolution and PixelShuffle(2) in one kernel
-        return self.body(x)                # a width that is not a multiple of 8: torch's convolution, the library's shuffle
+        return self.body(x)                # not an fp32 ROCm tensor, or the exact-fp32 switch is on: torch's convolution
 
 
 _SIDE_STREAMS = {}     # device index -> the second stream of two-stream inference (Restormer._forward_two_streams)
@@ -404,7 +404,8 @@ class Restormer(nn.Module):
                 return self._forward_bf16(inp_img)
             if self._bf16_widths_supported(inp_img):
                 return self._forward_bf16_train(inp_img)
-            # Training, or a width the packed bf16 kernels do not serve (e.g. the default dim=12): the fp32 kernels
+            # A channel width the packed bf16 kernels do not serve (e.g. the default dim=12), or an image whose width
+            # is not a multiple of 16: the fp32 kernels
             # on an fp32 copy of the input, result in the input's dtype -- the reference module runs under
             # autocast through ordinary torch operators, so such a call must not fail.
             with torch.autocast("cuda", enabled=False):
@@ -522,6 +523,8 @@ class Restormer(nn.Module):
     def _bf16_widths_supported(self, inp_img) -> bool:
         if not inp_img.is_cuda:
             return False
+        if inp_img.shape[-1] % 16:
+            return False           # the packed kernels take two pixels of a row per lane: the W / 8 level must be even
         ok = getattr(self, "_bf16_widths_ok", None)
         if ok is None:
             import ctypes

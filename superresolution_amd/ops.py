@@ -303,8 +303,9 @@ def pixel_shuffle2(x):
 # ----------------------------------------------------------------------------
 def conv3x3_backward(x, dy, weight, mode: int, want_dx: bool, want_bias: bool):
     """Gradients of conv2d(x, weight, bias, padding=1) (+ PixelUnshuffle(2) / PixelShuffle(2) for mode 1 / 2) from the
-    gradient of its output: (dx or None, dweight, dbias or None) through rst_conv3x3_bwd (exact-fp32 products); shapes it
-    does not take (W not a multiple of 4) go through torch's convolution gradients."""
+    gradient of its output: (dx or None, dweight, dbias or None) through rst_conv3x3_bwd (exact-fp32 products); a shape
+    it does not take (an odd width in front of a PixelUnshuffle, which the reference cannot run either) goes through
+    torch's convolution gradients."""
     lib = _lib.load()
     x, dy, w = _require(x, "conv3x3 x"), _require(dy, "conv3x3 dy"), _require(weight, "conv3x3 weight")
     B, Cin, H, W = x.shape
@@ -431,7 +432,10 @@ class _Conv3x3Fn(torch.autograd.Function):
             raise RuntimeError(f"conv3x3: weight {tuple(w.shape)} / bias do not match {Cin} input channels")
         shape = {0: (B, Cout, H, W), 1: (B, 4 * Cout, H // 2, W // 2), 2: (B, Cout // 4, 2 * H, 2 * W)}[mode]
         y = torch.empty(shape, dtype=x.dtype, device=x.device)
-        ws = workspace(lib.rst_conv3x3_workspace_bytes(Cin, Cout), x.device)
+        nb = lib.rst_conv3x3_fwd_workspace_bytes(B, Cin, Cout, H, W, int(mode))
+        if nb == 0:
+            raise RuntimeError(f"conv3x3: shape Cin={Cin} Cout={Cout} {H}x{W} mode={mode} is not supported")
+        ws = workspace(nb, x.device)
         check(lib.rst_conv3x3_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), B, Cin, Cout, H, W, int(mode), _ptr(ws), ws.numel(),
                                   _stream()), "rst_conv3x3_fwd")
         ctx.save_for_backward(x, w)

@@ -163,7 +163,7 @@ def test_activations_beyond_the_f16_range_never_return_inf():
 
 def test_input_contract_of_the_module():
     """What the reference's callers may hand the network (model/Restromer.py:385-433): non-contiguous views are
-    accepted and give the result of their contiguous copy (to the run-to-run spread of the atomics); a shape the network cannot take (not 4-D, H or W not a
+    accepted and give the result of their contiguous copy, bit for bit; a shape the network cannot take (not 4-D, H or W not a
     multiple of 8 -- the reference fails inside torch.cat there) is refused with a message, before any kernel runs;
     an empty batch is refused too."""
     from superresolution_amd.model.Restromer import Restormer
@@ -172,19 +172,52 @@ def test_input_contract_of_the_module():
     big = torch.rand(2, 3, 40, 48, device="cuda")
     view = big[:, :, 4:36, 8:40]                                   # 32 x 32 window, strides of the larger tensor
     assert not view.is_contiguous()
-    # Two runs on the same values differ in the last bit (the Gram matrix is summed over pixel ranges with
-    # floating-point atomics, in the order the blocks arrive), so "the same result" means to 2e-6 here.
     with torch.no_grad():
         a = net(view)
         b = net(view.contiguous())
-    torch.testing.assert_close(a, b, rtol=0, atol=2e-6)
+    assert torch.equal(a, b)
     window = big[:, :, :32, :32]
     chan_last = window.contiguous(memory_format=torch.channels_last)
     assert not chan_last.is_contiguous()
     with torch.no_grad():
-        torch.testing.assert_close(net(chan_last), net(window.contiguous()), rtol=0, atol=2e-6)
+        assert torch.equal(net(chan_last), net(window.contiguous()))
     for bad in (torch.rand(3, 32, 32, device="cuda"), torch.rand(1, 3, 30, 32, device="cuda"), torch.rand(1, 3, 32, 36, device="cuda")):
         with pytest.raises(RuntimeError):
             net(bad)
     with pytest.raises(RuntimeError):
         net(torch.rand(0, 3, 32, 32, device="cuda"))
+
+
+@pytest.mark.parametrize("hw", [(40, 40), (16, 104), (8, 8)])
+def test_image_sizes_with_odd_deep_levels(hw, monkeypatch):
+    """Any H, W divisible by 8 is an input of the reference (model/Restromer.py:385-433); the W / 8 level is then 5, 13
+    or 1 pixels wide.  fp32 forward against the fp64 oracle, with torch's own convolution made unavailable (every
+    convolution of the call is the library's); a bf16 input of such a size is served by the fp32 kernels (the packed
+    ones take two pixels of a row per lane) and comes back in bf16; the backward runs and gives finite gradients equal
+    to those of a second call."""
+    from oracle import restormer_oracle as orc
+    case = recipe.MODEL_CASES[1]
+    net, _, _ = _net(case)
+    sd64, _, _ = recipe.model_case_tensors(case, torch.float64)
+    img = recipe.make_input((1, case[2][1]) + hw, 5, "uniform", torch.float32)
+    with torch.no_grad():
+        ref = orc.restormer_forward(img.double(), sd64)
+
+    def no_torch_conv(*a, **k):
+        raise AssertionError("torch's convolution was called")
+    with monkeypatch.context() as m:
+        m.setattr(torch.nn.functional, "conv2d", no_torch_conv)
+        with torch.no_grad():
+            out = net.eval()(img.cuda())
+            out_bf = net(img.cuda().bfloat16())
+        net.train()
+        grads = []
+        for _ in range(2):
+            net.zero_grad()
+            net(img.cuda()).abs().mean().backward()
+            grads.append([p.grad.clone() for p in net.parameters()])
+    assert float((out.double().cpu() - ref).abs().max() / ref.abs().max()) < TOL
+    assert out_bf.dtype == torch.bfloat16
+    assert float((out_bf.double().cpu() - ref).abs().max() / ref.abs().max()) < 2e-2
+    for g0, g1 in zip(*grads):
+        assert torch.isfinite(g0).all() and torch.equal(g0, g1)
