@@ -217,9 +217,12 @@ int rst_conv3x3_fewout_up2_fwd(const float* x, const float* weight, const float*
 /* of 4 / 2 rows; a width that is not a multiple of 8 runs on a copy with zero   */
 /* columns added in the workspace), mode 1: even H and W, mode 2: Cout % 4 == 0  */
 /* (rst_conv3x3_supported).  The workspace holds the split weights             */
-/* (rst_conv3x3_workspace_bytes: enough whenever W % 8 == 0) and the padded      */
-/* copies (rst_conv3x3_fwd_workspace_bytes: enough for the shape given; 0 for    */
-/* an unsupported one).                                                          */
+/* (rst_conv3x3_workspace_bytes: enough whenever W % 8 == 0 and the exact-fp32   */
+/* switch is off) and the padded copies; rst_conv3x3_fwd_workspace_bytes is      */
+/* enough for the shape given under the current state of rst_set_exact_fp32      */
+/* (0 for an unsupported shape).  With the switch on the product runs on the     */
+/* exact-fp32 instruction over the nine shifted copies of the input, written to  */
+/* the workspace per chunk of samples (at most 1 GiB at a time).                 */
 /* ------------------------------------------------------------------------- */
 size_t rst_conv3x3_workspace_bytes(int32_t Cin, int32_t Cout);
 size_t rst_conv3x3_fwd_workspace_bytes(int32_t B, int32_t Cin, int32_t Cout, int32_t H, int32_t W, int32_t shuffle_mode);

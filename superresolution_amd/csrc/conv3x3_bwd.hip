@@ -212,6 +212,72 @@ int conv3x3_bwd_launch(const float* x, const float* dy, const float* w, float* d
     return RST_OK;
 }
 
+// ---- forward on the exact-fp32 matrix instruction (rst_set_exact_fp32(1): activations beyond the f16 range) ----------
+// y' = Wm col(x) + bias through the kernels of the backward above: Wm[co][(tap, ci)] = w[co][ci][tap], col(x) written per
+// chunk of samples (at most 1 GiB of it at a time), the shuffle of mode 1 / 2 as its own pass.  Nine times the input in
+// extra traffic: the price of the rarely taken exact route, not a tuned kernel.
+namespace {
+
+__global__ void __launch_bounds__(256)
+conv3_wm_kernel(const float* __restrict__ w, float* __restrict__ wm, int Cout, int Cin) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)Cout * 9 * Cin) return;
+    const int ci = (int)(i % Cin), tap = (int)((i / Cin) % 9), co = (int)(i / (9 * (int64_t)Cin));
+    wm[i] = w[((int64_t)co * Cin + ci) * 9 + tap];
+}
+
+int conv3_exact_chunk(int B, int Cin, int64_t N) {
+    const int64_t per = 9 * (int64_t)Cin * N;
+    const int64_t fit = ((int64_t)1 << 28) / (per > 0 ? per : 1);
+    return (int)(fit < 1 ? 1 : fit > B ? B : fit);
+}
+
+}  // namespace
+
+size_t conv3x3_exact_ws_bytes(int B, int Cin, int Cout, int H, int W, int mode) {
+    const int64_t N = (int64_t)H * W;
+    const int bs = conv3_exact_chunk(B, Cin, N);
+    CarveF cv(nullptr);
+    cv.floats((size_t)Cout * 9 * Cin);
+    cv.floats((size_t)bs * 9 * Cin * N);
+    if (mode != 0) cv.floats((size_t)bs * Cout * N);
+    return cv.total();
+}
+
+int conv3x3_exact_launch(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int H, int W, int mode,
+                         void* ws, size_t ws_bytes, hipStream_t stream) {
+    RST_REQUIRE(x && w && y && B > 0 && W % 4 == 0, "conv3x3 (exact fp32): bad operand");
+    RST_REQUIRE(aligned16(x) && aligned16(y), "conv3x3: tensors must be 16-byte aligned");
+    const size_t need = conv3x3_exact_ws_bytes(B, Cin, Cout, H, W, mode);
+    if (ws == nullptr || !aligned16(ws) || ws_bytes < need)
+        return fail(RST_ERR_WORKSPACE, "conv3x3 (exact fp32): workspace %zu < %zu bytes (rst_conv3x3_fwd_workspace_bytes)", ws_bytes, need);
+    const int64_t N = (int64_t)H * W;
+    const int bs = conv3_exact_chunk(B, Cin, N);
+    CarveF cv(ws);
+    float* wm = cv.floats((size_t)Cout * 9 * Cin);
+    float* col = cv.floats((size_t)bs * 9 * Cin * N);
+    float* tmp = mode != 0 ? cv.floats((size_t)bs * Cout * N) : nullptr;
+    const int64_t nw = (int64_t)Cout * 9 * Cin;
+    hipLaunchKernelGGL(conv3_wm_kernel, dim3((unsigned)cdiv(nw, 256)), dim3(256), 0, stream, w, wm, Cout, Cin);
+    RST_LAUNCH_CHECK();
+    for (int b0 = 0; b0 < B; b0 += bs) {
+        const int nb = B - b0 < bs ? B - b0 : bs;
+        RST_TRY(im2col_launch(x + (int64_t)b0 * Cin * N, col, nb, Cin, H, W, stream));
+        float* yb = y + (int64_t)b0 * Cout * N;           // every mode writes Cout * H * W values per sample
+        GemmNN g{};
+        g.A = wm; g.a_s1 = 0; g.a_s2 = 0; g.lda = 9 * Cin; g.transA = 0;
+        g.M = Cout; g.K = 9 * Cin;
+        g.X = col; g.x_s1 = (int64_t)9 * Cin * N; g.x_s2 = 0; g.ldx = N;
+        g.Y = mode != 0 ? tmp : yb; g.y_s1 = (int64_t)Cout * N; g.y_s2 = 0; g.ldy = N;
+        g.bias = bias;
+        g.N = N; g.nb1 = nb; g.nb2 = 1;
+        RST_TRY(gemm_nn_launch(g, stream));
+        if (mode == 1) RST_TRY(pixel_shuffle2_launch(false, tmp, yb, nb, Cout, H / 2, W / 2, stream));
+        if (mode == 2) RST_TRY(pixel_shuffle2_launch(true, tmp, yb, nb, Cout / 4, H, W, stream));
+    }
+    return RST_OK;
+}
+
 }  // namespace rst
 
 using namespace rst;

@@ -422,12 +422,16 @@ size_t conv3x3_f16s_ws_bytes(int Cin, int Cout) {
 }
 
 // workspace of a call: the split weights, and for a width that is not a multiple of 8 the padded input and result
-size_t conv3x3_f16s_fwd_ws_bytes(int B, int Cin, int Cout, int H, int W) {
-    size_t n = round_up(conv3x3_f16s_ws_bytes(Cin, Cout), (size_t)256);
-    if (!c3_kernel_width(W)) {
-        const size_t Wp = (size_t)round_up(W, 8);
+// (the first part: what the kernels of the current state of the exact-fp32 switch need at a width they take)
+static size_t c3_inner_ws_bytes(int B, int Cin, int Cout, int H, int Wk, int mode) {
+    const size_t n = gemm_f16s_enabled() ? conv3x3_f16s_ws_bytes(Cin, Cout) : conv3x3_exact_ws_bytes(B, Cin, Cout, H, Wk, mode);
+    return (size_t)round_up(n, 256);
+}
+size_t conv3x3_f16s_fwd_ws_bytes(int B, int Cin, int Cout, int H, int W, int mode) {
+    const int Wp = (int)round_up(W, 8);
+    size_t n = c3_inner_ws_bytes(B, Cin, Cout, H, Wp, mode);
+    if (!c3_kernel_width(W))
         n += round_up((size_t)B * Cin * H * Wp * 4, (size_t)256) + round_up((size_t)B * Cout * H * Wp * 4, (size_t)256);
-    }
     return n;
 }
 
@@ -438,11 +442,11 @@ int conv3x3_f16s_launch(const float* x, const float* w, const float* bias, float
                 "conv3x3: unsupported shape Cin=%d Cout=%d H=%d W=%d mode=%d (unshuffle: even H and W; shuffle: Cout %% 4 == 0)", Cin, Cout, H, W, mode);
     RST_REQUIRE(aligned16(x) && aligned16(y), "conv3x3: tensors must be 16-byte aligned");
     if (!c3_kernel_width(W)) {
-        const size_t need = conv3x3_f16s_fwd_ws_bytes(B, Cin, Cout, H, W);
+        const size_t need = conv3x3_f16s_fwd_ws_bytes(B, Cin, Cout, H, W, mode);
         if (ws == nullptr || ws_bytes < need || !aligned16(ws))
             return fail(RST_ERR_WORKSPACE, "conv3x3: workspace %zu < %zu bytes (rst_conv3x3_fwd_workspace_bytes)", ws_bytes, need);
-        const int Wp = round_up(W, 8);
-        const size_t wb = round_up(conv3x3_f16s_ws_bytes(Cin, Cout), (size_t)256);
+        const int Wp = (int)round_up(W, 8);
+        const size_t wb = c3_inner_ws_bytes(B, Cin, Cout, H, Wp, mode);
         const size_t xb = round_up((size_t)B * Cin * H * Wp * 4, (size_t)256);
         float* xp = reinterpret_cast<float*>(static_cast<char*>(ws) + wb);
         float* yp = reinterpret_cast<float*>(static_cast<char*>(ws) + wb + xb);
@@ -453,6 +457,7 @@ int conv3x3_f16s_launch(const float* x, const float* w, const float* bias, float
         const int f2 = mode == 1 ? 1 : mode == 2 ? 4 : 2;             // twice the width factor
         return copy_cols_launch(yp, y, rows, Wp * f2 / 2, W * f2 / 2, stream);
     }
+    if (!gemm_f16s_enabled()) return conv3x3_exact_launch(x, w, bias, y, B, Cin, Cout, H, W, mode, ws, ws_bytes, stream);
     if (ws == nullptr || ws_bytes < conv3x3_f16s_ws_bytes(Cin, Cout) || !aligned16(ws))
         return fail(RST_ERR_WORKSPACE, "conv3x3: workspace %zu < %zu bytes", ws_bytes, conv3x3_f16s_ws_bytes(Cin, Cout));
     static const bool fewin_off = getenv("RST_CONV_FEWIN") != nullptr && getenv("RST_CONV_FEWIN")[0] == '0';   // A/B runs
@@ -509,11 +514,10 @@ size_t rst_conv3x3_workspace_bytes(int32_t Cin, int32_t Cout) {
 }
 size_t rst_conv3x3_fwd_workspace_bytes(int32_t B, int32_t Cin, int32_t Cout, int32_t H, int32_t W, int32_t shuffle_mode) {
     if (B <= 0 || !rst::conv3x3_f16s_supported(Cin, Cout, H, W, shuffle_mode)) return 0;
-    return rst::conv3x3_f16s_fwd_ws_bytes(B, Cin, Cout, H, W);
+    return rst::conv3x3_f16s_fwd_ws_bytes(B, Cin, Cout, H, W, shuffle_mode);
 }
 int32_t rst_conv3x3_supported(int32_t Cin, int32_t Cout, int32_t H, int32_t W, int32_t shuffle_mode) {
-    // (with the exact-fp32 switch on there is no kernel for it here: callers fall back to their own convolution)
-    return rst::gemm_f16s_enabled() && rst::conv3x3_f16s_supported(Cin, Cout, H, W, shuffle_mode) ? 1 : 0;
+    return rst::conv3x3_f16s_supported(Cin, Cout, H, W, shuffle_mode) ? 1 : 0;
 }
 int rst_conv3x3_fwd(const float* x, const float* weight, const float* bias, float* y, int32_t B, int32_t Cin, int32_t Cout,
                     int32_t H, int32_t W, int32_t shuffle_mode, void* workspace, size_t workspace_bytes, void* stream) {

@@ -152,6 +152,10 @@ int conv3x3_fewout_launch(const Conv3Args& a, hipStream_t stream);
 int pixel_shuffle2_launch(bool shuffle, const float* src, float* dst, int B, int C, int H, int W, hipStream_t stream);
 // conv3x3_f16s.hip: dst[r][c] = c < ws ? src[r][c] : 0 over rows of ws -> wd values (zero columns added, or a crop)
 int copy_cols_launch(const float* src, float* dst, int64_t rows, int ws, int wd, hipStream_t stream);
+// conv3x3_bwd.hip: the dense 3x3 forward on the exact-fp32 matrix instruction (W a multiple of 4)
+size_t conv3x3_exact_ws_bytes(int B, int Cin, int Cout, int H, int W, int mode);
+int conv3x3_exact_launch(const float* x, const float* w, const float* bias, float* y, int B, int Cin, int Cout, int H, int W, int mode,
+                         void* ws, size_t ws_bytes, hipStream_t stream);
 
 // ---- attn_small.hip ----
 int attn_softmax_launch(const float* gram_partial, const float* sqq_partial, const float* sqk_partial,

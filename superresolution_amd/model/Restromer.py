@@ -172,7 +172,7 @@ class OverlapPatchEmbed(nn.Module):
     def forward(self, x):
         if ops.conv3x3_supported(x, self.proj.weight, 0):
             return ops.conv3x3(x, self.proj.weight, self.proj.bias, 0)
-        return self.proj(x)            # not an fp32 ROCm tensor, or the exact-fp32 switch is on: torch's convolution
+        return self.proj(x)            # not an fp32 ROCm tensor (a CPU copy of the module): torch's convolution
 
 
 class _Permute(nn.Module):
@@ -200,7 +200,7 @@ class Downsample(nn.Module):
         conv = self.body[0]
         if ops.conv3x3_supported(x, conv.weight, 1):
             return ops.conv3x3(x, conv.weight, conv.bias, 1)        # convolution and PixelUnshuffle(2) in one kernel
-        return self.body(x)                # not an fp32 ROCm tensor, or the exact-fp32 switch is on: torch's convolution
+        return self.body(x)                # not an fp32 ROCm tensor (a CPU copy of the module): torch's convolution
 
 
 class Upsample(nn.Module):
@@ -216,7 +216,7 @@ class Upsample(nn.Module):
         conv = self.body[0]
         if ops.conv3x3_supported(x, conv.weight, 2):
             return ops.conv3x3(x, conv.weight, conv.bias, 2)        # convolution and PixelShuffle(2) in one kernel
-        return self.body(x)                # not an fp32 ROCm tensor, or the exact-fp32 switch is on: torch's convolution
+        return self.body(x)                # not an fp32 ROCm tensor (a CPU copy of the module): torch's convolution
 
 
 _SIDE_STREAMS = {}     # device index -> the second stream of two-stream inference (Restormer._forward_two_streams)

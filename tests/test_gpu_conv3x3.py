@@ -52,6 +52,27 @@ def test_conv3x3_vs_oracle(B, Cin, Cout, H, W, mode, bias):
     assert err < TOL, err
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W,mode,bias", [c for i, c in enumerate(CASES) if i % 3 == 0])
+def test_conv3x3_on_the_exact_fp32_instructions(B, Cin, Cout, H, W, mode, bias):
+    """rst_set_exact_fp32(1): the same entry point on the exact-fp32 matrix instruction (nine shifted copies + one
+    product), with activations far beyond the f16 range of the default route."""
+    from superresolution_amd import _lib, ops
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B * 1000 + Cin + Cout + H + W + mode + 1)
+    x = torch.randn(B, Cin, H, W, generator=g) * 3.0e5
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (3.0 * Cin ** 0.5)
+    b = torch.randn(Cout, generator=g) * 1.0e5 if bias else None
+    lib.rst_set_exact_fp32(1)
+    try:
+        assert ops.conv3x3_supported(x.cuda(), w.cuda(), mode)
+        y = ops.conv3x3(x.cuda(), w.cuda(), None if b is None else b.cuda(), mode)
+    finally:
+        lib.rst_set_exact_fp32(0)
+    ref = _ref(x, w, b, mode)
+    assert tuple(y.shape) == tuple(ref.shape) and torch.isfinite(y).all()
+    assert float((y.double().cpu() - ref).abs().max() / ref.abs().max()) < TOL
+
+
 def test_conv3x3_image_scale_inputs_and_borders():
     """Image-like input (all positive, mean far from zero) and a weight of ones: every border pixel must see exactly its
     zero padding (a wrong halo shows as an O(1) error)."""
