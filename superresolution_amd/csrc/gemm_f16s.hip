@@ -11,7 +11,9 @@
 //     pieces 64 B apart so that the four lane groups of a fragment read four different bank quarters), and every wave
 //     converts the fragments of its own 32 pixels while it reads them (the sums for a folded LayerNorm fall out).
 // Lane group g of a fragment holds channels {2 g + 8 j + e : j < 4, e < 2} of the chunk -- for both operands alike.
-// 8 waves = 2 row halves x 4 pixel quarters, block tile (32 RT rows) x 128 pixels, 3-deep ring, one barrier per chunk.
+// 8 waves = 2 row halves x 4 pixel quarters, block tile (32 RT rows) x 128 pixels, one barrier per chunk; two blocks of
+// at most 128 rows per compute unit with a 2-deep ring each (or, RST_GF_ONE_BLOCK=1, one block of up to 256 rows with a
+// 3-deep ring).
 // |x| must stay below 65504 (f16 range); RST_F32_MFMA=1 keeps every product on the exact-fp32 kernels.
 #include "kernels.hpp"
 #include <atomic>
@@ -26,7 +28,17 @@ typedef _Float16 gf_h8 __attribute__((ext_vector_type(8)));
 typedef float gf_f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 gf_h2 __attribute__((ext_vector_type(2)));
 
-constexpr int GF_BN = 128, GF_BK = 32, GF_STAGES = 3, GF_XPIECE = 272, GF_SCR_LD = 36;
+// Timing experiments only (results are wrong): -DGF_ABL=1 every weight-fragment piece re-reads one address, 2 every pixel
+// piece does, 3 no stores, 4 no matrix instructions, 5 no conversion and no matrix instructions.  Measured on the 40
+// LayerNorm-folded products of a 16 x 3 x 256 x 256 forward pass with one block of 192 rows per compute unit (3.08 ms):
+// 1: 3.10 (the 9 GB of weight fragments that come out of L2 per pass cost nothing), 3: 2.50, 4: 2.32, 5: 1.99 -- two
+// thirds of the time is what is left when nothing is computed: per block one exposed round trip for its first chunk,
+// 6 to 12 barriers, and the stores.  Two smaller blocks per unit hide each other's share of that: 3.08 -> 2.98 ms, the
+// products with a residual 1.80 -> 1.59 ms, although every pixel is then converted twice as often.
+#ifndef GF_ABL
+#define GF_ABL 0
+#endif
+constexpr int GF_BN = 128, GF_BK = 32, GF_XPIECE = 272, GF_SCR_LD = 36;
 
 // One block of four waves per 16-row tile (and matrix); wave w splits chunks w, w + 4, ...
 __global__ void __launch_bounds__(256)
@@ -71,9 +83,14 @@ gemm_f16s_prep_kernel(const float* __restrict__ w, int64_t w_bs, int lda, int tr
     }
 }
 
-template <int RT, bool RES, bool LN>
-__global__ void __launch_bounds__(512)
+// GF_STAGES = 3: one block per compute unit (up to 256 rows), two chunks in flight.  GF_STAGES = 2: at most 128 rows
+// and 128 registers, so that TWO blocks share a compute unit (at most 67 KB of LDS each): a block lives for 6 to 15
+// chunks only, and its prologue (the first chunk's round trip) and epilogue (the stores) hide behind the other
+// block's products, which one block per unit cannot do.
+template <int RT, bool RES, bool LN, int GF_STAGES>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(GF_STAGES == 2 ? 4 : 2, GF_STAGES == 2 ? 4 : 2)))
 gemm_f16s_kernel(GemmNN g, int mblocks, int mtiles, int kch, int walk) {
+    static_assert(GF_STAGES == 3 || RT <= 4, "two blocks per compute unit: at most 128 rows");
     constexpr int A_FLOATS = 2 * RT * 2 * 256;            // 2 RT tiles x (hi, lo) x 1 KiB
     constexpr int STAGE = A_FLOATS + 16 * GF_XPIECE;
     constexpr int NP = 4 * RT + 16, P = (NP + 7) / 8;     // DMA pieces per chunk, per wave
@@ -142,6 +159,8 @@ gemm_f16s_kernel(GemmNN g, int mblocks, int mtiles, int kch, int walk) {
         for (int i = 0; i < P; ++i) {
             float* dst = dsto[i] >= 0 ? st + dsto[i] : ring + GF_STAGES * STAGE;
             const char* src = (isx[i] ? xbase : abase) + (lastc ? poff_last[i] : poff[i]);
+            if (GF_ABL == 1 && !isx[i]) src = static_cast<const char*>(g.afrag) + lane * 16;
+            if (GF_ABL == 2 && isx[i]) src = reinterpret_cast<const char*>(g.X) + lane * 16;
             __builtin_amdgcn_global_load_lds((gf_gptr)src, (gf_lptr)dst, 16, 0, 0);
         }
     };
@@ -161,28 +180,21 @@ gemm_f16s_kernel(GemmNN g, int mblocks, int mtiles, int kch, int walk) {
         acc2[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc2[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
-    constexpr int LNN = LN ? RT : 1;
-    f32x4 lns[LNN], lnc[LNN];
-    if constexpr (LN) {
-#pragma unroll
-        for (int i = 0; i < RT; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + mh * 16 * RT + 16 * i + 4 * kk + r;
-                const int mc = m < g.M ? m : g.M - 1;
-                lns[i][r] = g.ln_s[mc];
-                lnc[i][r] = g.ln_c[mc];
-            }
-    }
 
     issue(0);
-    issue(kch > 1 ? 1 : 0);
+    if (GF_STAGES == 3) issue(kch > 1 ? 1 : 0);
     for (int c = 0; c < kch; ++c) {
         // chunk c landed for this wave (chunk c + 1 may stay in flight), then for everyone; the barrier also frees
         // the stage of chunk c - 1 for the refill
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(P) : "memory");
-        issue(c + 2 < kch ? c + 2 : kch - 1);
+        if (GF_STAGES == 3) {
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(P) : "memory");
+            issue(c + 2 < kch ? c + 2 : kch - 1);
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (c + 1 < kch) issue(c + 1);
+        }
         const float* st = ring + (c % GF_STAGES) * STAGE;
+        if (GF_ABL == 5) continue;
         // fragments of this wave's 2 x 16 pixels: lane (pixel lm, group kk) takes rows 2 kk + 8 j + e
         gf_h8 xh[2], xl[2];
         const float* xs = st + A_FLOATS + kk * GF_XPIECE + nq * 32 + lm;
@@ -216,6 +228,10 @@ gemm_f16s_kernel(GemmNN g, int mblocks, int mtiles, int kch, int walk) {
             }
         }
         const gf_h8* af = reinterpret_cast<const gf_h8*>(st) + mh * RT * 2 * 64 + lane;
+        if (GF_ABL == 4) {
+            asm volatile("" :: "v"(xh[0]), "v"(xh[1]), "v"(xl[0]), "v"(xl[1]));
+            continue;
+        }
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
             const gf_h8 ah = af[(i * 2 + 0) * 64], al = af[(i * 2 + 1) * 64];
@@ -259,8 +275,12 @@ gemm_f16s_kernel(GemmNN g, int mblocks, int mtiles, int kch, int walk) {
             float v0 = fmaf(acc2[i][0][r], 1.0f / 2048.f, acc1[i][0][r]);
             float v1 = fmaf(acc2[i][1][r], 1.0f / 2048.f, acc1[i][1][r]);
             if constexpr (LN) {
-                v0 = fmaf(rstd[0], fmaf(tco[0], lns[i][r], v0), lnc[i][r]);
-                v1 = fmaf(rstd[1], fmaf(tco[1], lns[i][r], v1), lnc[i][r]);
+                // (read here, not ahead of the main loop: eight registers per row tile that the products do not have)
+                const int m = m0 + mh * 16 * RT + 16 * i + 4 * kk + r;
+                const int mc = m < g.M ? m : g.M - 1;
+                const float lns = g.ln_s[mc], lnc = g.ln_c[mc];
+                v0 = fmaf(rstd[0], fmaf(tco[0], lns, v0), lnc);
+                v1 = fmaf(rstd[1], fmaf(tco[1], lns, v1), lnc);
             }
             sl[(4 * kk + r) * GF_SCR_LD + lm] = v0;
             sl[(4 * kk + r) * GF_SCR_LD + 16 + lm] = v1;
@@ -270,7 +290,7 @@ gemm_f16s_kernel(GemmNN g, int mblocks, int mtiles, int kch, int walk) {
             const int row = rr + 8 * h;
             f32x4 v = *reinterpret_cast<const f32x4*>(&sl[row * GF_SCR_LD + c4]);
             const int m = m0 + mh * 16 * RT + 16 * i + row;
-            if (m < g.M && nok) {
+            if (m < g.M && nok && GF_ABL != 3) {
                 if constexpr (RES) {
                     const float rs = RSb ? RSb[m] : 1.f;
                     const f32x4 rv = *reinterpret_cast<const f32x4*>(Rb + (int64_t)m * g.ldr + n);
@@ -288,10 +308,10 @@ gemm_f16s_kernel(GemmNN g, int mblocks, int mtiles, int kch, int walk) {
 }
 
 // rows per block = 32 RT: least padding, ties to the larger tile (the pixel tile is re-read once per row block)
-int gf_pick_rt(int M) {
+int gf_pick_rt(int M, int rt_max) {
     int best = 1;
     int64_t best_pad = INT64_MAX;
-    for (int rt = 8; rt >= 1; --rt) {
+    for (int rt = rt_max; rt >= 1; --rt) {
         const int64_t pad = cdiv(M, 32 * rt) * 32 * rt;
         if (pad < best_pad) { best_pad = pad; best = rt; }
     }
@@ -343,23 +363,30 @@ int gemm_f16s_launch(const GemmNN& g, hipStream_t stream) {
                 "gemm_f16s: the second input tensor needs a split at a multiple of 32 channels");
     RST_REQUIRE(g.ln_mode == 0 || (g.ln_s && g.ln_c && g.R == nullptr && !g.accumulate && g.bias == nullptr && g.K % 2 == 0),
                 "gemm_f16s: folded LayerNorm takes no residual / bias / accumulation and an even channel count");
-    const int rt = gf_pick_rt(g.M);
+    // two blocks per compute unit (see the kernel) unless RST_GF_ONE_BLOCK=1 (A/B runs)
+    static const bool one_block = getenv("RST_GF_ONE_BLOCK") != nullptr && getenv("RST_GF_ONE_BLOCK")[0] == '1';
+    const int stages = one_block ? 3 : 2;
+    const int rt = gf_pick_rt(g.M, one_block ? 8 : g.ln_mode != 0 ? 3 : 4);      // (the LayerNorm form spills at 4 x 32 rows)
     const int mblocks = (int)cdiv(g.M, 32 * rt), mtiles = (int)cdiv(g.M, 16), kch = (int)cdiv(g.K, 32);
     const int64_t gx = cdiv(g.N, GF_BN) * mblocks;
     RST_REQUIRE(gx < (1ll << 31), "gemm_f16s: grid too large");
     dim3 grid((unsigned)gx, (unsigned)(g.nb1 * g.nb2)), blk(512);
-    const size_t lds = sizeof(float) * (size_t)(GF_STAGES * (2 * rt * 2 * 256 + 16 * GF_XPIECE) + 256);
+    const size_t lds = sizeof(float) * (size_t)(stages * (2 * rt * 2 * 256 + 16 * GF_XPIECE) + 256);
     const double nb = (double)g.nb1 * g.nb2;
     ProfScope prof(stream, g.ln_mode ? "gemm_f16s_ln" : "gemm_f16s", 2.0 * g.M * g.K * g.N * nb,
                    4.0 * nb * g.N * (g.K + g.M * (1.0 + (g.R ? 1.0 : 0.0) + (g.accumulate ? 1.0 : 0.0))));
     const void* kern = nullptr;
-#define GF_PICK(RTV)                                                                                   \
-    case RTV:                                                                                          \
-        kern = g.ln_mode != 0 ? reinterpret_cast<const void*>(&gemm_f16s_kernel<RTV, false, true>)     \
-             : g.R            ? reinterpret_cast<const void*>(&gemm_f16s_kernel<RTV, true, false>)     \
-                              : reinterpret_cast<const void*>(&gemm_f16s_kernel<RTV, false, false>);   \
+#define GF_PICK(RTV, STG)                                                                                   \
+    case RTV:                                                                                               \
+        kern = g.ln_mode != 0 ? reinterpret_cast<const void*>(&gemm_f16s_kernel<RTV, false, true, STG>)     \
+             : g.R            ? reinterpret_cast<const void*>(&gemm_f16s_kernel<RTV, true, false, STG>)     \
+                              : reinterpret_cast<const void*>(&gemm_f16s_kernel<RTV, false, false, STG>);   \
         break;
-    switch (rt) { GF_PICK(1) GF_PICK(2) GF_PICK(3) GF_PICK(4) GF_PICK(5) GF_PICK(6) GF_PICK(7) GF_PICK(8) default: return fail(RST_ERR_INVALID, "gemm_f16s: bad tile"); }
+    if (stages == 2) {
+        switch (rt) { GF_PICK(1, 2) GF_PICK(2, 2) GF_PICK(3, 2) GF_PICK(4, 2) default: return fail(RST_ERR_INVALID, "gemm_f16s: bad tile"); }
+    } else {
+        switch (rt) { GF_PICK(1, 3) GF_PICK(2, 3) GF_PICK(3, 3) GF_PICK(4, 3) GF_PICK(5, 3) GF_PICK(6, 3) GF_PICK(7, 3) GF_PICK(8, 3) default: return fail(RST_ERR_INVALID, "gemm_f16s: bad tile"); }
+    }
 #undef GF_PICK
     KernelSetup su;
     RST_TRY(kernel_setup(kern, 512, lds, &su));
