@@ -3,16 +3,16 @@
 // shape the resident-weight kernel (gemm_nn_res.hip) does not take.
 //
 // 8 waves per block (2 row halves x 4 pixel quarters), block tile
-// (32*MTW rows) x 128 pixels, K walked in chunks of 16 through a 3-deep LDS ring
+// (32*MTW rows) x 128 pixels, K walked in chunks of 16 through a 2-deep LDS ring
 // that is filled by LDS-DMA only (global_load_lds, 16 B per lane: no staging
 // registers, no address arithmetic in the VALU beyond one pointer per piece):
 //   A chunk  [rows][16 k]   k contiguous: one 1-KiB piece = 16 rows; an MFMA lane
 //            (m, kk) takes its four k-steps with a single ds_read_b128 -- the
 //            k order inside a chunk is k = 4*kk + s, identically for both operands
 //   X chunk  [16 k][128 px] one piece = 2 k-rows
-// Each wave issues exactly two pieces per chunk, so the wait for chunk c is the
-// counted `s_waitcnt vmcnt(2)` (chunk c+1 stays in flight), then one
-// barrier, then the refill of the slot freed by chunk c-1.
+// Each wave issues exactly two pieces per chunk, so the wait for chunk c is a
+// counted `s_waitcnt vmcnt(2 (GD_STAGES - 2))` (the chunks behind c stay in
+// flight), then one barrier, then the refill of the slot freed by chunk c-1.
 // With TRANSA the A chunk is stored [16 k][rows] like X (memory is K-major).
 // Exact fp32 (v_mfma_f32_16x16x4_f32).
 #include "kernels.hpp"
@@ -21,7 +21,14 @@ namespace rst {
 
 constexpr int GD_BN = 128;
 constexpr int GD_BK = 16;
-constexpr int GD_STAGES = 3;
+// Ring depth.  Two stages = 36 KB of LDS (the epilogue's transpose buffers are the larger part) and 62 registers: FOUR blocks (32 waves) per compute unit, each with one chunk
+// in flight.  Measured on the residual products of a 16 x 3 x 256 x 256 forward pass (48 launches, same box): 2 stages
+// 6.83 ms, 3 stages (three blocks per unit) 7.03, 4 stages 8.09, 5 stages 7.87; the residual requested ahead of the
+// pixel stream 7.31 -- residency, not the depth of a block's own pipeline, is what keeps the memory system busy.
+#ifndef GD_STG
+#define GD_STG 2
+#endif
+constexpr int GD_STAGES = GD_STG;
 constexpr int GD_SCR_LD = 36;
 
 typedef __attribute__((address_space(1))) const void* gd_gptr;
@@ -35,7 +42,9 @@ gemm_nn_dma_kernel(GemmNN g, int mblocks) {
     constexpr int A_FLOATS = 128 * GD_BK;               // always 8 pieces (rows clamped), see header
     constexpr int X_FLOATS = GD_BK * GD_BN;
     constexpr int STAGE = A_FLOATS + X_FLOATS;
-    __shared__ __attribute__((aligned(16))) float ring[GD_STAGES * STAGE];
+    // (the epilogue reuses the ring as eight wave-private transpose buffers of 2 x 16 x GD_SCR_LD floats: 36 KB, four blocks per unit still fit)
+    constexpr int SCR_FLOATS = 8 * 2 * 16 * GD_SCR_LD;
+    __shared__ __attribute__((aligned(16))) float ring[GD_STAGES * STAGE > SCR_FLOATS ? GD_STAGES * STAGE : SCR_FLOATS];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int lm = lane & 15, kk = lane >> 4;
@@ -109,15 +118,15 @@ gemm_nn_dma_kernel(GemmNN g, int mblocks) {
             }
     }
 
-    // prologue: two chunks in flight (re-issuing the last chunk keeps the per-wave count fixed)
-    issue(0);
-    issue(nchunks > 1 ? 1 : 0);
+    // prologue: GD_STAGES - 1 chunks in flight (re-issuing the last chunk keeps the per-wave count fixed)
+#pragma unroll
+    for (int c = 0; c < GD_STAGES - 1; ++c) issue(c < nchunks ? c : nchunks - 1);
 
     for (int c = 0; c < nchunks; ++c) {
-        // chunk c landed for this wave (chunk c+1 = 2 pieces may stay in flight), then for everyone;
+        // chunk c landed for this wave (the chunks behind it may stay in flight), then for everyone;
         // the same barrier says every wave is done reading chunk c-1, whose slot is refilled next
-        asm volatile("s_waitcnt vmcnt(2)\n\ts_barrier" ::: "memory");
-        issue(c + 2 < nchunks ? c + 2 : nchunks - 1);          // always two pieces per step per wave
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(2 * (GD_STAGES - 2)) : "memory");
+        issue(c + GD_STAGES - 1 < nchunks ? c + GD_STAGES - 1 : nchunks - 1);          // always two pieces per step per wave
         const float* st = ring + (c % GD_STAGES) * STAGE;
         const bool kvalid = c * GD_BK + 4 * kk < g.K;          // K % 4 == 0: a lane's four k are all valid or all past K
         f32x4 a4[MTW];
