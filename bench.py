@@ -196,7 +196,9 @@ def roofline_from(prof, traffic_of=lambda name: None):
                 "frac": round(achieved / PEAK_HBM_GBS, 4)}
     peaks = measured_peaks()
     if peaks:
-        key = {"mfma": "mfma_f32_16x16x4_TFLOPs", "hbm": "copy_GBps"}[roof["bound"]]
+        # hbm: the best read + write stream measured on the device (c = a + b by torch's elementwise kernel where the
+        # peaks file has it, else the library's copy kernel)
+        key = {"mfma": "mfma_f32_16x16x4_TFLOPs", "hbm": "stream_GBps" if "stream_GBps" in peaks else "copy_GBps"}[roof["bound"]]
         if key in peaks and (roof["bound"] == "hbm" or mpeak == PEAK_FP32_MATRIX_TFLOPS):
             roof["measured_peak"] = peaks[key]
             roof["frac_of_measured_peak"] = round(achieved / peaks[key], 4)

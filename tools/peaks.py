@@ -1,7 +1,7 @@
 """What this MI355X delivers on a streaming copy / read and on bare MFMA loops (rst_peak_copy / rst_peak_mfma),
 next to the paper peaks that bench.py's roofline fractions use.  Writes one JSON object (stdout, and --out FILE).
 
-    python tools/peaks.py --out profiles/r2_peaks.json
+    python tools/peaks.py --out profiles/r3_peaks.json
 """
 import argparse
 import json
@@ -45,6 +45,18 @@ def measure():
     t = _time(lambda: b.copy_(a), 20)
     out["torch_copy_GBps"] = 2 * nbytes / t / 1e9
     del a, b
+    # the mixes the network's memory-bound kernels have, by torch's elementwise kernels on 800 MB operands:
+    # c = a + b (two reads, one write: a residual product), a += 1 (read and write of the same lines), a fill
+    n = 200 * 1024 * 1024
+    x, y, z = (torch.rand(n, device="cuda") for _ in range(3))
+    t = _time(lambda: torch.add(x, y, out=z), 20)
+    out["triad_GBps"] = 12 * n / t / 1e9
+    t = _time(lambda: x.add_(1.0), 20)
+    out["inplace_GBps"] = 8 * n / t / 1e9
+    t = _time(lambda: z.fill_(1.0), 20)
+    out["fill_GBps"] = 4 * n / t / 1e9
+    out["stream_GBps"] = max(out["copy_GBps"], out["torch_copy_GBps"], out["triad_GBps"])     # best read + write stream
+    del x, y, z
     iters = 4000
     buf = torch.empty(256 * 8 * 256, dtype=torch.float32, device="cuda")
     for kind, name, k in ((0, "mfma_f32_16x16x4", 4), (1, "mfma_bf16_16x16x32", 32), (2, "mfma_f16_16x16x32", 32)):
