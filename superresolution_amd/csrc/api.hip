@@ -70,10 +70,13 @@ struct LnIn {
 static size_t ln_fold_floats(int Cout, int Cin) { return (size_t)round_up(Cout, 16) * round_up(Cin, 32) + 2 * (size_t)round_up(Cout, 16); }
 
 // Products with at least this many input channels run on the f16 matrix instructions with split operands
-// (gemm_f16s.hip: 159 -> 98 us / 151 -> 77 us for the LayerNorm-folded products at 192 / 384 channels); below it the
-// exact-fp32 kernels are HBM-bound already (96 channels at 256 x 256: 277 us against 334).  RST_F16S_MINK overrides (tests, A/B runs).
+// (gemm_f16s.hip: 159 -> 98 us / 151 -> 77 us for the LayerNorm-folded products at 192 / 384 channels).  At 96 channels
+// the exact-fp32 kernel, whose matrix pipe is half busy there, used to win (277 us against 334 at 256 x 256); since
+// two blocks of the split-f16 kernel share a compute unit it is the other way round (the residual products of a
+// 16 x 3 x 256 x 256 forward pass: 8.52 -> 8.09 ms per step with the bound at 96, 8.24 at 48).  RST_F16S_MINK
+// overrides (tests, A/B runs).
 static int f16s_min_k() {
-    static const int v = getenv("RST_F16S_MINK") != nullptr ? atoi(getenv("RST_F16S_MINK")) : 192;
+    static const int v = getenv("RST_F16S_MINK") != nullptr ? atoi(getenv("RST_F16S_MINK")) : 96;
     return v;
 }
 static bool use_f16s(const GemmNN& g) { return gemm_f16s_enabled() && g.K >= f16s_min_k() && gemm_f16s_supported(g); }
