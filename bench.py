@@ -289,7 +289,7 @@ def _timed(step, steps, warmup, world):
 
 
 def side_train_bf16(dev, rank, world, steps=8, warmup=3, B=8, S=128):
-    """BASELINE config 3 beside the default line: the bf16 training step (forward, L1, backward, gradient all-reduce
+    """The bf16 training configuration beside the default line: the bf16 training step (forward, L1, backward, gradient all-reduce
     over RCCL, division by the world size, clip, Adam) on 8 x 3 x 128 x 128 per GPU, and the same step with the
     collectives replaced by no-ops -- the difference is what the exchange costs a step."""
     from superresolution_amd.parallel import Collectives, DataParallelTrainer, NullCollectives
@@ -322,7 +322,7 @@ def side_train_bf16(dev, rank, world, steps=8, warmup=3, B=8, S=128):
 
 
 def side_tiled_2048(net, dev, rank, world, steps=3, warmup=1):
-    """BASELINE config 4 beside the default line: one 2048 x 2048 image in 256-pixel tiles + 32 pixels of overlap,
+    """The tiled-image configuration beside the default line: one 2048 x 2048 image in 256-pixel tiles + 32 pixels of overlap,
     tile t on rank t mod world, the cores gathered on rank 0 (bf16 storage path)."""
     from superresolution_amd.parallel import Collectives, tiled_inference
     img = torch.rand(1, 3, 2048, 2048, device=dev, generator=torch.Generator(device=dev).manual_seed(300)).bfloat16()
@@ -479,7 +479,7 @@ def main():
         out["bf16_storage"]["two_streams"] = {"value": round(world * B * S * S * args.steps / 1e6 / el2, 3), "unit": "MP/s",
                                               "ms_per_step": round(el2 / args.steps * 1e3, 3),
                                               "note": "opt-in (model.two_streams = True): the batch as two half-batches on two HIP streams"}
-        # The default line also carries the two workloads whose data path has an exchange: BASELINE config 3 (bf16
+        # The default line also carries the two workloads whose data path has an exchange: the training configuration (bf16
         # training step, gradient all-reduce) and config 4 (one 2048 x 2048 image in tiles dealt to the ranks, cores
         # gathered on rank 0).  Under torch.distributed.run they go through RCCL as they are (also with one rank), so a
         # 1/2/4/8-GPU sweep of the default command records them; in a plain one-process run they run without.  Never `value`.

@@ -452,7 +452,7 @@ class Restormer(nn.Module):
         return out
 
     def _forward_bf16_train(self, inp_img):
-        """Differentiable forward with bf16 activations (BASELINE config 3: bf16 storage, fp32 sums, fp32 master
+        """Differentiable forward with bf16 activations (the bf16 training configuration: bf16 storage, fp32 sums, fp32 master
         parameters and gradients), on the library's packed tensors from the first layer to the last: every stage of
         TransformerBlocks is one autograd node that runs the packed bf16 kernels forward and, per block, either saves
         the intermediates its backward reads (while they fit) or keeps only the bf16 input and evaluates the block

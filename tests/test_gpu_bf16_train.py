@@ -1,4 +1,4 @@
-"""Training with bf16 activations (BASELINE config 3's precision: bf16 storage, fp32 sums, fp32 master parameters):
+"""Training with bf16 activations (the precision of the bf16 training configuration: bf16 storage, fp32 sums, fp32 master parameters):
 gradients against the fp64 oracle / the reference-generated fixture, and a short optimiser trajectory against the
 oracle's.  Tolerances are bf16's: a block rounds its activations to 8 significant bits six times, the network has
 44 blocks; measured values are quoted next to each bound."""

@@ -1,4 +1,4 @@
-"""BASELINE configs 4 and 5 at their FULL sizes (the other GPU tests stop at 272 x 480 frames and 48 x 64 tiles):
+"""The tiled 2048 x 2048 image and the 2160 x 3840 frame at their FULL sizes (the other GPU tests stop at 272 x 480 frames and 48 x 64 tiles):
 one untiled 2160 x 3840 frame -- 8.3 M pixels through the split-K Gram sums, tensors past 2^31 bytes -- and one
 2048 x 2048 image in 256-pixel tiles with 32 pixels of overlap.  The CPU oracle takes minutes per frame, so the anchors
 are paths the smaller tests already hold against it: the row-sharded frame evaluation (tests/test_gpu_sharded_frame.py)
