@@ -480,7 +480,7 @@ def main():
                                               "ms_per_step": round(el2 / args.steps * 1e3, 3),
                                               "note": "opt-in (model.two_streams = True): the batch as two half-batches on two HIP streams"}
         # The default line also carries the two workloads whose data path has an exchange: the training configuration (bf16
-        # training step, gradient all-reduce) and config 4 (one 2048 x 2048 image in tiles dealt to the ranks, cores
+        # training step, gradient all-reduce) and the tiled image (one 2048 x 2048 image in tiles dealt to the ranks, cores
         # gathered on rank 0).  Under torch.distributed.run they go through RCCL as they are (also with one rank), so a
         # 1/2/4/8-GPU sweep of the default command records them; in a plain one-process run they run without.  Never `value`.
         # (a failure here -- the same on every rank, e.g. out of memory -- is recorded, not fatal to the line)
