@@ -317,8 +317,6 @@ static int attention_tail(const rst_block_desc* d, const rst_block_params* p, At
                                     B, heads, c, b.plan.splits, stream));
     }
     }
-    RST_TRY(attn_fold_launch(p->proj_weight, b.attn, b.mfold, B, C, heads, c, stream));
-
     // y = Mfold[b] v (+bias) (+residual)
     GemmNN g2{};
     g2.A = b.mfold; g2.a_s1 = (int64_t)C * C; g2.a_s2 = 0; g2.lda = C; g2.transA = 0;
@@ -328,9 +326,12 @@ static int attention_tail(const rst_block_desc* d, const rst_block_params* p, At
     g2.bias = d->conv_bias ? p->proj_bias : nullptr;
     g2.M = C; g2.K = C; g2.N = N; g2.nb1 = B; g2.nb2 = 1; g2.accumulate = 0;
     if (use_f16s(g2)) {
+        // (the fold kernel writes the split-f16 operand fragments of Mfold itself: no preparation launch per block)
         const int64_t fb = (int64_t)gemm_f16s_frag_bytes(C, C);
-        RST_TRY(gemm_f16s_prep_launch(b.mfold, (int64_t)C * C, B, C, 0, nullptr, nullptr, nullptr, C, C, b.mfrag, fb, nullptr, nullptr, stream));
+        RST_TRY(attn_fold_f16s_launch(p->proj_weight, b.attn, b.mfold, b.mfrag, fb, B, C, heads, c, stream));
         g2.afrag = b.mfrag; g2.afrag_s1 = fb; g2.afrag_s2 = 0;
+    } else {
+        RST_TRY(attn_fold_launch(p->proj_weight, b.attn, b.mfold, B, C, heads, c, stream));
     }
     return gemm_nn_launch(g2, stream);
 }

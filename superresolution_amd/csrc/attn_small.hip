@@ -103,7 +103,9 @@ attn_fold_kernel(const float* __restrict__ wo,      // [C][C]
                  float* __restrict__ mfold,         // [B][C][C] or null
                  bf16_t* __restrict__ frag,         // or null: Mfold[b] as bf16 operand fragments (layout of pk_prep_a_kernel)
                  int64_t frag_bs, int KS,
-                 int C, int heads, int c) {
+                 int C, int heads, int c,
+                 _Float16* __restrict__ frag16,     // or null: Mfold[b] as split-f16 operand fragments (layout of gemm_f16s_prep_kernel)
+                 int64_t frag16_bs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // W^T: c x 16, then A: c*c
     float* Wt = smem;
     float* As = smem + 16 * c;
@@ -143,6 +145,28 @@ attn_fold_kernel(const float* __restrict__ wo,      // [C][C]
             // rows past C are padding of the fragment buffer: their weights were staged as zeros, so acc is zero
             uint16_t* fo = reinterpret_cast<uint16_t*>(frag) + (int64_t)b * frag_bs + fold_frag_index(m0 + 4 * rq, h * c + j, KS);
             fo[0] = to_bf16_bits(acc.x); fo[8] = to_bf16_bits(acc.y); fo[16] = to_bf16_bits(acc.z); fo[24] = to_bf16_bits(acc.w);
+        }
+        if (frag16 != nullptr) {
+            // [16-row tile][32-column chunk][hi, lo][lane = row + 16 g][8]: lane group g holds columns 2 g + 8 i + e of the chunk
+            const int k = h * c + j, kc = k >> 5, kin = k & 31;
+            const int64_t at = ((((int64_t)blockIdx.x * KS + kc) * 2) * 64 + 4 * rq + 16 * ((kin & 7) >> 1)) * 8 + 2 * (kin >> 3) + (kin & 1);
+            _Float16* fo = frag16 + (int64_t)b * frag16_bs + at;
+            const float v[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const _Float16 hi = (_Float16)v[e];
+                fo[8 * e] = hi;
+                fo[8 * e + 64 * 8] = (_Float16)((v[e] - (float)hi) * 2048.f);
+            }
+        }
+    }
+    if (frag16 != nullptr && h == heads - 1) {
+        const int kpad = 32 * KS - C;
+        for (int t = tid; t < 16 * kpad; t += 256) {
+            const int r = t / kpad, k = C + t - r * kpad, kc = k >> 5, kin = k & 31;
+            const int64_t at = ((((int64_t)blockIdx.x * KS + kc) * 2) * 64 + r + 16 * ((kin & 7) >> 1)) * 8 + 2 * (kin >> 3) + (kin & 1);
+            frag16[(int64_t)b * frag16_bs + at] = (_Float16)0.f;
+            frag16[(int64_t)b * frag16_bs + at + 64 * 8] = (_Float16)0.f;
         }
     }
     // contraction positions past C (up to a multiple of 32) are padding as well: the last head's blocks clear them
@@ -335,7 +359,27 @@ int attn_fold_frag_launch(const float* wo, const float* attn, float* mfold, bf16
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((unsigned)(frag != nullptr ? ntiles : cdiv(C, 16)), (unsigned)heads, (unsigned)B);
     ProfScope prof(stream, "attn_fold", 2.0 * B * C * C * c, 4.0 * B * (2.0 * C * C + (double)heads * c * c));
-    hipLaunchKernelGGL(attn_fold_kernel, grid, dim3(256), lds, stream, wo, attn, mfold, frag, frag_bs, KS, C, heads, c);
+    hipLaunchKernelGGL(attn_fold_kernel, grid, dim3(256), lds, stream, wo, attn, mfold, frag, frag_bs, KS, C, heads, c,
+                       static_cast<_Float16*>(nullptr), (int64_t)0);
+    RST_LAUNCH_CHECK();
+    return RST_OK;
+}
+
+// As attn_fold_launch; the folded matrices also leave as the split-f16 operand fragments of gemm_f16s (what
+// gemm_f16s_prep_launch would make of mfold: rows padded to 16, columns to 32 with zeros), frag_bytes apart per sample.
+int attn_fold_f16s_launch(const float* wo, const float* attn, float* mfold, void* frag, int64_t frag_bytes, int B, int C, int heads,
+                          int c, hipStream_t stream) {
+    const size_t lds = (size_t)(c * c + 16 * c) * sizeof(float);
+    RST_REQUIRE(lds <= 160 * 1024, "attention: channels per head %d too large for the fold kernel", c);
+    RST_REQUIRE(frag != nullptr && frag_bytes % 16 == 0 && (size_t)frag_bytes >= gemm_f16s_frag_bytes(C, C),
+                "attention fold: fragment buffer too small");
+    if (lds > 64 * 1024)
+        RST_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fold_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((unsigned)cdiv(C, 16), (unsigned)heads, (unsigned)B);
+    ProfScope prof(stream, "attn_fold", 2.0 * B * C * C * c, 4.0 * B * (2.0 * C * C + (double)heads * c * c));
+    hipLaunchKernelGGL(attn_fold_kernel, grid, dim3(256), lds, stream, wo, attn, mfold, static_cast<bf16_t*>(nullptr), (int64_t)0,
+                       (int)cdiv(C, 32), C, heads, c, static_cast<_Float16*>(frag), frag_bytes / 2);
     RST_LAUNCH_CHECK();
     return RST_OK;
 }

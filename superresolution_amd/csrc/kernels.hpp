@@ -162,6 +162,8 @@ int attn_softmax_launch(const float* gram_partial, const float* sqq_partial, con
                         const float* temperature, float* attn, float* ghat, float* nq, float* nk,
                         int B, int heads, int c, int splits, hipStream_t stream);
 int attn_fold_launch(const float* wo, const float* attn, float* mfold, int B, int C, int heads, int c, hipStream_t stream);
+int attn_fold_f16s_launch(const float* wo, const float* attn, float* mfold, void* frag, int64_t frag_bytes, int B, int C, int heads,
+                          int c, hipStream_t stream);
 int attn_fold_frag_launch(const float* wo, const float* attn, float* mfold, uint16_t* frag, int64_t frag_bs, int ntiles, int KS,
                           int B, int C, int heads, int c, hipStream_t stream);
 
