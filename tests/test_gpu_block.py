@@ -109,13 +109,17 @@ def test_unfused_pair_still_matches():
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-2000:]
 
 
-@pytest.mark.parametrize("switch", [{"RST_F32_MFMA": "1"}, {"RST_PWDW_FORM": "f"}, {"RST_PWDW_FORM": "w"}, {"RST_F16S_MINK": "48"}],
-                         ids=["exact_fp32_mfma", "single_role_split_f16", "wave_specialised", "split_f16_gemm_everywhere"])
+@pytest.mark.parametrize("switch", [{"RST_F32_MFMA": "1"}, {"RST_PWDW_FORM": "f"}, {"RST_PWDW_FORM": "w"}, {"RST_F16S_MINK": "48"},
+                                    {"RST_F16S_MINK": "192"}, {"RST_GF_ONE_BLOCK": "1"}],
+                         ids=["exact_fp32_mfma", "single_role_split_f16", "wave_specialised", "split_f16_gemm_everywhere",
+                              "split_f16_gemm_from_192", "split_f16_gemm_one_block_per_cu"])
 def test_product_routes_forced(switch):
     """The MFMA-bound products of the fp32 path run on the f16 matrix instructions with split operands by default.
     RST_F32_MFMA=1 keeps them on the exact-fp32 instruction (the route for activations beyond the f16 range);
     RST_PWDW_FORM=f / w forces the single-role / wave-specialised fused kernel wherever it supports the shape;
-    RST_F16S_MINK=48 sends every 1x1 product from 48 input channels through the split-f16 GEMM.  Each route must pass the
+    RST_F16S_MINK=48 sends every 1x1 product from 48 input channels through the split-f16 GEMM, 192 keeps the 96-channel
+    ones on the exact-fp32 kernel (the default bound is 96); RST_GF_ONE_BLOCK=1 runs the split-f16 GEMM as one block of
+    up to 256 rows per compute unit with a 3-deep ring instead of two smaller ones.  Each route must pass the
     golden block cases (switches are read once per process: child run)."""
     import os
     import subprocess
